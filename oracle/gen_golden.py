@@ -1,0 +1,267 @@
+"""TEST INFRASTRUCTURE ONLY -- emits tests/golden/*.npz|json by running the REAL reference glue.
+
+Run in the build container (needs /root/reference):   python -m oracle.gen_golden [--only NAME]
+Each fixture stores outputs of the reference (oracle/ref_harness.py) on seeded synthetic weights/inputs
+(oracle_amd/synth.py regenerates the inputs bit-identically anywhere), never reference source text.
+Large tensors are stored as a strided subset plus checksums.
+"""
+import argparse
+import json
+import os
+import random
+
+import numpy as np
+import torch
+
+from oracle import cpu_ref as cr
+from oracle import ref_harness as rh
+from oracle_amd.dims import TINY, Dims
+from oracle_amd.synth import CHAIN_BASE, CHAIN_LEN, install_chain, synth_images, synth_state
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+
+
+def _f32(x):
+    return x.detach().float().numpy()
+
+
+def sub2(x, s0, s1):
+    """Strided subset over the last two dims + checksums of the full tensor."""
+    x = x.detach().float()
+    return {'sub': x[..., ::s0, ::s1].numpy(), 'sum': np.float64(x.double().sum().item()),
+            'abssum': np.float64(x.double().abs().sum().item()), 'shape': np.array(x.shape)}
+
+
+def save(name, **arrs):
+    flat = {}
+    for k, v in arrs.items():
+        if isinstance(v, dict):
+            for kk, vv in v.items():
+                flat[f'{k}.{kk}'] = vv
+        else:
+            flat[k] = v
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **flat)
+    print('wrote', path, os.path.getsize(path) // 1024, 'KiB')
+
+
+# test prompts (synthetic ids; -200 = <image>, 18610 = visual descriptor placeholder, 0 = pad)
+def ids_batch3():
+    rows = [[1, 5, 6, -200, 7, 8, 9, 10, 11], [1, 21, -200, 22, 23], [1, 31, 32, 33, 34, 35, -200, 36, 37, 38, 39, 40]]
+    L = max(len(r) for r in rows)
+    return torch.tensor([[0] * (L - len(r)) + r for r in rows])
+
+
+def ids_desc(n_desc=7):
+    row = [1, 50, -200, 51, 52]
+    for j in range(n_desc):
+        row += [18610, 60 + j, 70 + j]
+    return torch.tensor([row + [90, 91]])
+
+
+def gen_vision(dtype_name):
+    """G1/G2: CLIP penultimate features, pooled and projected features, V in {1,3,4} (TINY depth) and the
+    full 24-layer tower for 3 views."""
+    dtype = getattr(torch, dtype_name)
+    st = synth_state(TINY, seed=0, dtype=dtype)
+    model, cfg = rh.build_reference_model(TINY, st, dtype=dtype)
+    out = {}
+    with torch.inference_mode():
+        for V in (1, 3, 4):
+            imgs = synth_images(2, V, TINY).to(dtype)                       # (2,V,3,H,W) or (2,3,H,W)
+            flat = imgs if V == 1 else imgs.flatten(0, 1)
+            vt = model.get_vision_tower()(flat)
+            out[f'vt_V{V}'] = sub2(vt, 37, 41)
+            if V == 1:
+                feats = model.encode_images_pooled(imgs, None)
+            else:
+                feats = model.encode_images_pooled(flat, [V, V])
+            out[f'learned_V{V}'] = sub2(feats, 37, 29)
+        # ragged views per row (training-style list input): rows with 2 and 4 views
+        a = synth_images(1, 2, TINY, seed=77).to(dtype)[0]
+        b = synth_images(1, 4, TINY, seed=78).to(dtype)[0]
+        feats = model.encode_images_pooled(torch.cat([a, b]), [2, 4])
+        out['learned_ragged24'] = sub2(feats, 37, 29)
+        # other mv types through the reference's own dispatch (llava_arch.py:203-239)
+        imgs = synth_images(2, 3, TINY).to(dtype)
+        ids = torch.tensor([[1, 5, -200, 6], [1, 7, -200, 8]])
+        for mv in ('concat', 'concat_pooled', 'max', 'avg'):
+            model.config.mv_type = mv
+            r = model.prepare_inputs_labels_for_multimodal(ids, None, torch.ones_like(ids, dtype=torch.bool), None, None, imgs, None)
+            emb = r[4]
+            out[f'mv_{mv}'] = sub2(emb[:, 2:-1], 31, 29)     # the spliced image rows
+            out[f'mv_{mv}_T'] = np.array(emb.shape[1])
+        model.config.mv_type = 'learned'
+        g = model.get_vision_tower().global_forward(synth_images(2, 1, TINY).to(dtype))
+        out['global_pooler_output'] = _f32(g)
+    save(f'vision_tiny_{dtype_name}', **out)
+
+
+def gen_vision_full():
+    """Full-depth CLIP (24 layers) for 3 views, bf16, through the reference tower."""
+    d = Dims(n_layers=1, d_model=512, n_heads=4, d_ff=1408)     # LLaMA part irrelevant here
+    st = synth_state(d, seed=3, dtype=torch.bfloat16)
+    model, cfg = rh.build_reference_model(d, st, dtype=torch.bfloat16)
+    imgs = synth_images(1, 3, d, seed=4321).to(torch.bfloat16)[0]
+    with torch.inference_mode():
+        vt = model.get_vision_tower()(imgs)
+        feats = model.encode_images_pooled(imgs, [3])
+    save('vision_full_bfloat16', vt=sub2(vt, 19, 23), learned=sub2(feats, 19, 23))
+
+
+def gen_splice():
+    """G3: exact index work of prepare_inputs_labels_for_multimodal (fp32 so rows are exact copies)."""
+    st = synth_state(TINY, seed=0, dtype=torch.float32)
+    model, cfg = rh.build_reference_model(TINY, st, dtype=torch.float32)
+    out = {}
+    torch.manual_seed(5)
+    with torch.inference_mode():
+        imgs = synth_images(3, 3, TINY).float()
+        feats = model.encode_images_pooled(imgs.flatten(0, 1), [3, 3, 3])
+        cases = {
+            'single': (ids_batch3()[2:3, :], None, 1),
+            'batch3': (ids_batch3(), None, 3),
+            'desc7': (ids_desc(7), [torch.randn(512) for _ in range(7)], 1),
+            'desc_multirow': (ids_desc(2), [torch.randn(3, 512), torch.randn(512)], 1),
+            'desc_missing': (ids_desc(7), None, 1),          # the llava_arch.py:305 quirk
+        }
+        for name, (ids, desc, nb) in cases.items():
+            mask0 = ids != 0
+            _, pos, am, _, emb, _ = model.prepare_inputs_labels_for_multimodal(ids, None, mask0, None, None, imgs[:nb], desc)
+            # identify each output row by matching it against its possible sources
+            out[f'{name}.ids'] = ids.numpy()
+            out[f'{name}.mask'] = am.numpy().astype(np.uint8)
+            out[f'{name}.emb_rowsum'] = emb.double().sum(-1).numpy()
+            out[f'{name}.emb_sub'] = emb[:, :, ::61].numpy()
+            # position_ids is None when not passed in (llava_arch.py:371-372); re-run passing positions
+            p_in = torch.arange(ids.shape[1])[None].expand(ids.shape[0], -1)
+            r = model.prepare_inputs_labels_for_multimodal(ids, p_in, mask0, None, None, imgs[:nb], desc)
+            out[f'{name}.pos'] = r[1].numpy()
+            if desc is not None:
+                out[f'{name}.desc'] = torch.cat([x.reshape(-1, 512) for x in desc]).numpy()
+        # right padding + truncation variant
+        model.config.tokenizer_padding_side = 'right'
+        model.config.tokenizer_model_max_length = 580
+        ids = ids_batch3()
+        p_in = torch.arange(ids.shape[1])[None].expand(ids.shape[0], -1)
+        r = model.prepare_inputs_labels_for_multimodal(ids, p_in, ids != 0, None, None, imgs, None)
+        out['right_trunc.ids'] = ids.numpy()
+        out['right_trunc.mask'] = r[2].numpy().astype(np.uint8)
+        out['right_trunc.pos'] = r[1].numpy()
+        out['right_trunc.emb_rowsum'] = r[4].double().sum(-1).numpy()
+    save('splice_tiny_float32', **out)
+
+
+def gen_llm(dtype_name):
+    """G4/G5: prefill last-token logits (top-16) and greedy tokens incl. EOS / ragged finishing."""
+    dtype = getattr(torch, dtype_name)
+    out = {}
+    for tag, peaked in (('rand', False), ('peak', True)):
+        st = synth_state(TINY, seed=0, dtype=dtype)
+        if peaked:
+            install_chain(st, TINY)
+        model, cfg = rh.build_reference_model(TINY, st, dtype=dtype)
+        imgs = synth_images(3, 3, TINY).to(dtype)
+        ids = chain_prompts() if peaked else ids_batch3()
+        with torch.inference_mode():
+            mask0 = ids != 0
+            # position ids as GenerationMixin.prepare_inputs_for_generation derives them from the mask
+            p_in = mask0.long().cumsum(-1) - 1
+            p_in.masked_fill_(~mask0, 1)
+            o = model(input_ids=ids, attention_mask=mask0, position_ids=p_in, images=imgs, use_cache=True)
+            logits = o.logits[:, -1].float()
+            top = torch.topk(logits, 16, dim=-1)
+            out[f'{tag}.ids'] = ids.numpy()
+            out[f'{tag}.top16_val'] = top.values.numpy()
+            out[f'{tag}.top16_idx'] = top.indices.numpy()
+            out[f'{tag}.logits_sub'] = logits[:, ::97].numpy()
+            out[f'{tag}.logits_absmax'] = logits.abs().max(-1).values.numpy()
+        gen = rh.reference_generate(model, cfg, ids, imgs, 40)
+        out[f'{tag}.generated'] = gen.numpy()
+        # check the restatement reproduces the tokens in this very run (same threads / same machine)
+        mine = cr.greedy_generate(st, TINY, ids, imgs, max_new_tokens=40)
+        assert torch.equal(mine, gen), (tag, mine[:, ids.shape[1]:], gen[:, ids.shape[1]:])
+    save(f'llm_tiny_{dtype_name}', **out)
+
+
+def chain_prompts():
+    ends = [CHAIN_BASE + CHAIN_LEN - 9, CHAIN_BASE + CHAIN_LEN - 30, CHAIN_BASE + CHAIN_LEN - 17]
+    rows = [[1, 5, 6, -200, 7, 8, 9, 10, ends[0]], [1, 21, -200, 22, ends[1]], [1, 31, 32, 33, 34, 35, -200, 36, 37, 38, 39, ends[2]]]
+    L = max(len(r) for r in rows)
+    return torch.tensor([[0] * (L - len(r)) + r for r in rows])
+
+
+def gen_text():
+    """G6/G7: pure-python scene-graph helpers of the reference (scene_graph_converters.py)."""
+    ns = rh.load_reference()
+    cv = ns.converters
+    kat = {}
+    raw = [
+        'head surgeon,patient,cutting; assistant surgeon,head surgeon,assisting; nurse,instrument table,closeTo;',
+        '<SG> head surgeon, patient, drilling ; anaesthetist,anesthesia equipment,manipulating;</SG> trailing words',
+        'circulator,operating table,touching;broken,triplet;;  ;a,b,c,d; patient,operating table,lyingOn.</s>',
+        '</SG> x,y,z; <SG> q,r,s;',
+        '<s> nurse , secondary table , preparing ;</s>',
+        '',
+    ]
+    kat['parse'] = [{'in': s, 'out': [list(t) for t in cv.parse_llava_sg(s)]} for s in raw]
+    # temporal memory: a scripted 12-frame history under random.seed(42) (main.py:52 seeds `random` via pl.seed_everything)
+    ents = ['head surgeon', 'assistant surgeon', 'circulator', 'nurse', 'anaesthetist', 'patient', 'instrument table', 'operating table']
+    preds = ['assisting', 'cementing', 'cleaning', 'closeTo', 'cutting', 'drilling', 'holding', 'lyingOn', 'touching']
+    rng = random.Random(7)
+    hist = []
+    cur = set()
+    for t in range(12):
+        for _ in range(rng.randint(0, 3)):
+            s, o = rng.sample(ents, 2)
+            cur.add((s, rng.choice(preds), o))
+        if cur and rng.random() < 0.5:
+            cur.discard(rng.choice(sorted(cur)))
+        hist.append({'timepoint_idx': t * 3, 'scene_graph': sorted(cur)})
+    steps = []
+    random.seed(42)
+    for n in range(1, 13):
+        sg = cv.llava_sg_to_surgery_sg(hist[:n], entity_of_interest=None, IRRELEVANT_PREDS=['closeto', 'closeTo'])
+        tp = hist[n - 1]['timepoint_idx'] + 3
+        sg_f = [e for e in sg if e[0] < tp]
+        steps.append({'n': n, 'timepoint': tp,
+                      'surgery_sg': [[a, list(b)] for a, b in sg],
+                      'longshort': cv.surgery_sg_to_memory_str(sg_f, current_timepoint=tp, TEMPORAL_STYLE='longshort'),
+                      'short': cv.surgery_sg_to_memory_str(sg_f, current_timepoint=tp, TEMPORAL_STYLE='short'),
+                      'long': cv.surgery_sg_to_memory_str(sg_f, current_timepoint=tp, TEMPORAL_STYLE='long')})
+    kat['history'] = [{'timepoint_idx': h['timepoint_idx'], 'scene_graph': [list(x) for x in h['scene_graph']]} for h in hist]
+    kat['memory'] = steps
+    # conversation template (conversation.py conv_vicuna_v1) with a marker message
+    conv = ns.conversation.conv_templates['vicuna_v1'].copy()
+    conv.append_message(conv.roles[0], '<image>\nHELLO')
+    conv.append_message(conv.roles[1], None)
+    kat['vicuna_v1_prompt'] = conv.get_prompt()
+    kat['default_conversation_is_vicuna_v1'] = ns.conversation.default_conversation.name if hasattr(ns.conversation.default_conversation, 'name') else None
+    kat['sep2'] = conv.sep2
+    path = os.path.join(OUT, 'text_kat.json')
+    with open(path, 'w') as f:
+        json.dump(kat, f, indent=1, ensure_ascii=False)
+    print('wrote', path)
+
+
+ALL = {
+    'vision_f32': lambda: gen_vision('float32'),
+    'vision_bf16': lambda: gen_vision('bfloat16'),
+    'vision_full': gen_vision_full,
+    'splice': gen_splice,
+    'llm_f32': lambda: gen_llm('float32'),
+    'llm_bf16': lambda: gen_llm('bfloat16'),
+    'text': gen_text,
+}
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only', default=None)
+    a = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    for k, fn in ALL.items():
+        if a.only and a.only not in k:
+            continue
+        print('==', k)
+        fn()
