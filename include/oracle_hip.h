@@ -1,0 +1,109 @@
+/* liboracle_hip -- C ABI of the MI355X-native ORacle multi-view LLaVA inference engine.
+ *
+ * The reference (egeozsoy/ORacle) has no FFI for this path: its boundary is a Python API
+ * (SURVEY.md §8b). Every entry point below therefore names the reference Python function whose GPU work
+ * it replaces; the host-side mirror in oracle_amd/llava/ keeps those functions' signatures and calls
+ * these entry points through ctypes (binding shown in INTEGRATION.md).
+ *
+ * Conventions: extern "C"; plain pointers and sizes; return 0 on success, negative on error with a
+ * message in orc_last_error(); caller owns every buffer it passes (device pointers unless marked host);
+ * the engine owns its weight copies, KV cache and workspace; every call is asynchronous on `stream`
+ * (a hipStream_t passed as void*; NULL = default stream) unless noted; one engine is not thread-safe.
+ * All activations / weights are bf16 (uint16 storage), logits fp32, ids int32.
+ */
+#ifndef ORACLE_HIP_H
+#define ORACLE_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_engine orc_engine;
+
+typedef struct orc_config {
+  /* Vicuna/LLaMA (LlavaConfig; reference LLaVA/llava/model/language_model/llava_llama.py:27-46) */
+  int32_t vocab, d_model, n_layers, n_heads, d_ff;
+  float rms_eps, rope_theta;
+  /* CLIP vision tower (reference multimodal_encoder/clip_encoder.py:22-27) */
+  int32_t clip_layers, clip_d, clip_heads, clip_ff, clip_image, clip_patch;
+  float clip_eps;
+  /* learned multi-view pooler (reference multimodal_projector/builder.py:56-72) */
+  int32_t pool_layers, pool_heads, pool_ff, pool_maxpos;
+  float pool_eps;
+  /* capacities */
+  int32_t max_batch;      /* rows per generate() (<= 16) */
+  int32_t max_seq;        /* KV-cache slots per row: spliced prompt + new tokens */
+  int32_t max_images;     /* images per vision call */
+  int32_t max_new_tokens; /* capacity of the on-device generated-token buffer */
+  int32_t pad_token_id, eos_token_id;
+} orc_config;
+
+const char* orc_last_error(void);
+int orc_abi_version(void);
+
+/* load_pretrained_model (reference LLaVA/llava/model/builder.py:26-185): weight ingest. */
+int orc_engine_create(const orc_config* cfg, orc_engine** out);
+void orc_engine_destroy(orc_engine* e);
+/* `name` is the reference checkpoint key (e.g. "model.layers.0.self_attn.q_proj.weight"); data is bf16,
+ * row-major, `shape[ndim]`; on_device != 0 means `data` is a device pointer. Synchronous. */
+int orc_engine_load_weight(orc_engine* e, const char* name, const void* data, int on_device,
+                           const int64_t* shape, int ndim);
+/* packs weights into MFMA fragment order, builds rotary tables, allocates KV cache + workspace. Synchronous. */
+int orc_engine_finalize(orc_engine* e);
+
+/* CLIPVisionTower.forward + feature_select (reference clip_encoder.py:29-51):
+ * images (n,3,I,I) -> hidden_states[-2][:,1:] (n, patches, clip_d). */
+int orc_vision_encode(orc_engine* e, const void* images, int n_images, void* out_features, void* stream);
+/* CLIPVisionTower.global_forward (reference clip_encoder.py:53-64): pooler_output (n, clip_d). */
+int orc_vision_global(orc_engine* e, const void* images, int n_images, void* out_pooled, void* stream);
+/* pad_embeddings + ImageEmbeddingPooler.forward (reference llava_arch.py:143-183, projector/builder.py:74-82):
+ * features (sum(views), patches, clip_d) grouped per row by views_per_row (host, B ints)
+ * -> (B, patches, clip_d). */
+int orc_pool_views(orc_engine* e, const void* features, const int32_t* views_per_row_host, int batch,
+                   void* out_pooled, void* stream);
+/* mm_projector mlp2x_gelu (reference multimodal_projector/builder.py:41-48): (rows, clip_d) -> (rows, d_model). */
+int orc_project(orc_engine* e, const void* x, int rows, void* out, void* stream);
+/* multi-view reductions of llava_arch.py:216-227 (mode 0 max, 1 mean): (B,V,n) -> (B,n). */
+int orc_view_reduce(orc_engine* e, const void* x, int batch, int views, int64_t n, int mode, void* out, void* stream);
+/* encode_images_concat_pool (reference llava_arch.py:128-141): 2x2 max pool of the token grid. */
+int orc_pool2x2(orc_engine* e, const void* x, int n_images, int grid, int d, void* out, void* stream);
+
+/* prepare_inputs_labels_for_multimodal, step 0 (reference llava_arch.py:245-359): gather the spliced
+ * (rows, d_model) embedding matrix. codes[r] = kind<<28 | index; kind 0 = zero (padding) row,
+ * 1 = embed_tokens[index], 2 = image_features[index], 3 = descriptors[index]. */
+int orc_splice(orc_engine* e, const int32_t* codes, int rows, const void* image_features, const void* descriptors,
+               void* out_embeds, void* stream);
+
+/* LlavaLlamaForCausalLM.forward, step 0 of generate() (reference llava_llama.py:54-100): prefill over the
+ * left-padded (batch, T, d_model) embeddings; fills the KV cache; resets the greedy-search state; samples
+ * the first token. position_ids (batch*T, device); left_pad_host[b] = number of padding rows of row b.
+ * logits_out: optional device (batch, vocab) fp32 copy of the last-position logits. */
+int orc_prefill(orc_engine* e, const void* embeds, const int32_t* position_ids, const int32_t* left_pad_host,
+                int batch, int T, float* logits_out, void* stream);
+/* one KV-cached greedy step (reference llava_arch.py:192-201 + llava_llama.py:54-112 + greedy search):
+ * feeds forced_ids (device, batch ints) or, when NULL, the tokens sampled by the previous step. */
+int orc_decode_step(orc_engine* e, const int32_t* forced_ids, float* logits_out, void* stream);
+/* runs up to n_steps decode steps back to back on the stream (no host round trip). */
+int orc_decode_steps(orc_engine* e, int n_steps, void* stream);
+/* synchronises `stream` and reads the greedy-search state: tokens_host (batch * max_new_tokens, row-major),
+ * number of steps taken so far, rows still unfinished, raw argmax of the last step (batch ints, optional). */
+int orc_read_state(orc_engine* e, int32_t* tokens_host, int32_t* steps_host, int32_t* n_unfinished_host,
+                   int32_t* last_argmax_host, void* stream);
+
+/* test / profiling hooks for single kernels (same kernels the engine runs). */
+int orc_test_gemm(const void* x, int M, int K, const void* w_rowmajor, int N, const void* bias, const void* residual,
+                  int epilogue, int use_gemv, void* out, void* stream);
+int orc_test_rmsnorm(const void* x, const void* w, int rows, int d, float eps, void* out, void* stream);
+int orc_test_layernorm(const void* x, const void* w, const void* b, int rows, int d, float eps, void* out, void* stream);
+int orc_test_attention(const void* q, const void* k, const void* v, int B, int H, int Sq, int Sk, int head_dim,
+                       const int32_t* kbeg, const int32_t* kend, int causal, int q_off, float scale, void* out,
+                       void* stream);
+/* bytes of weights streamed by one decode step / bytes of KV read per cached key per row (roofline bookkeeping). */
+int64_t orc_decode_weight_bytes(orc_engine* e);
+int64_t orc_kv_bytes_per_key(orc_engine* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

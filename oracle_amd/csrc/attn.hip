@@ -1,0 +1,280 @@
+// Flash-style attention on v_mfma_f32_16x16x32_bf16 for the three dense attention shapes of the path:
+//   CLIP ViT (16 heads x 64, 577 tokens, no mask), pooler BERT (8 heads x 128, key-padding mask),
+//   LLaMA prefill (32 heads x 128, causal + left-pad mask).
+// and a split-KV streaming kernel for decode (one query per row, HBM-bound on the KV cache).
+//
+// Prefill kernel: one workgroup = 4 waves = 64 query rows, each wave 16 rows; K/V tiles of 32 keys staged
+// in LDS (XOR-swizzled so both the ds_read_b128 K reads and the ds_read_b64_tr_b16 V reads are
+// conflict-free). Orientation is chosen so that no data crosses lanes between the two products:
+//   S^T = K . Q^T   (A = K tile from LDS, B = Q^T fragment held in registers)  -> lane holds, for its
+//                    query column q = lane&15, keys 4g..4g+3 of each 16-key block (g = lane>>4)
+//   O^T = V^T . P^T (A = V^T via the transposing LDS read, B = P^T = the lane's own probabilities)
+// so row max / row sum / rescale are per-lane scalars (+2 shuffles across g), and the k-slot order of the
+// second product is simply defined as "the order the first product left the keys in".
+// Rounding points follow the reference's eager path: scores rounded to bf16 after QK^T and again after
+// the scale multiply; probabilities rounded to bf16 before PV (here before the final 1/l).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+template <int HD> __device__ __forceinline__ int fK(int key) { return HD == 128 ? (key & 15) : ((key >> 1) & 7); }
+template <int HD> __device__ __forceinline__ int fV(int key) { return HD == 128 ? (key & 7) : ((key >> 1) & 3); }
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
+  constexpr int KB = 32;
+  constexpr int ROWB = HD * 2;
+  constexpr int CH = HD / 8;   // 16-byte chunks per key row
+  __shared__ __attribute__((aligned(16))) char sK[KB * ROWB];
+  __shared__ __attribute__((aligned(16))) char sV[KB * ROWB];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int g = lane >> 4, r16 = lane & 15;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int qblk = blockIdx.x * 64;
+  const int kb_ = a.kbeg ? a.kbeg[b] : 0;
+  const int ke_ = a.kend ? a.kend[b] : a.Sk;
+
+  const int qrow = qblk + w * 16 + r16;
+  const int qrow_c = qrow < a.Sq ? qrow : a.Sq - 1;
+  const bf16_t* qp = a.Q + (size_t)b * a.q_bs + (size_t)h * a.q_hs + (size_t)qrow_c * a.q_ts;
+  bf16x8 qf[HD / 32];
+#pragma unroll
+  for (int kk = 0; kk < HD / 32; ++kk) qf[kk] = *(const bf16x8*)(qp + kk * 32 + g * 8);
+
+  int q_hi = qblk + 63;
+  if (q_hi > a.Sq - 1) q_hi = a.Sq - 1;
+  int k_hi = ke_;
+  if (a.causal && q_hi + a.q_off + 1 < k_hi) k_hi = q_hi + a.q_off + 1;
+  const int qi = qrow + a.q_off;
+
+  f32x4 o[HD / 16];
+#pragma unroll
+  for (int i = 0; i < HD / 16; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = -INFINITY, l = 0.f;
+
+  const bf16_t* kbase = a.K + (size_t)b * a.k_bs + (size_t)h * a.k_hs;
+  const bf16_t* vbase = a.V + (size_t)b * a.v_bs + (size_t)h * a.v_hs;
+
+  for (int k0 = (kb_ / KB) * KB; k0 < k_hi; k0 += KB) {
+    __syncthreads();
+    for (int c = tid; c < KB * CH; c += 256) {
+      const int key = c / CH, ch = c % CH;
+      int gk = k0 + key;
+      gk = gk < a.Sk ? gk : a.Sk - 1;
+      const u32x4 kv = *(const u32x4*)(kbase + (size_t)gk * a.k_ts + ch * 8);
+      const u32x4 vv = *(const u32x4*)(vbase + (size_t)gk * a.v_ts + ch * 8);
+      *(u32x4*)(sK + key * ROWB + ((ch ^ fK<HD>(key)) << 4)) = kv;
+      *(u32x4*)(sV + key * ROWB + ((((ch >> 1) ^ fV<HD>(key)) << 5) | ((ch & 1) << 4))) = vv;
+    }
+    __syncthreads();
+
+    float s[8];
+#pragma unroll
+    for (int kb2 = 0; kb2 < 2; ++kb2) {
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int key_l = kb2 * 16 + r16;
+#pragma unroll
+      for (int kk = 0; kk < HD / 32; ++kk) {
+        const int c = kk * 4 + g;
+        const bf16x8 kf = *(const bf16x8*)(sK + key_l * ROWB + ((c ^ fK<HD>(key_l)) << 4));
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key_abs = k0 + kb2 * 16 + 4 * g + r;
+        const bool ok = key_abs >= kb_ && key_abs < ke_ && (!a.causal || key_abs <= qi);
+        const float sc = rbf(rbf(acc[r]) * a.scale);
+        s[kb2 * 4 + r] = ok ? sc : -INFINITY;
+      }
+    }
+    float tm = s[0];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) tm = fmaxf(tm, s[j]);
+    tm = fmaxf(tm, __shfl_xor(tm, 16, 64));
+    tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+    const float m_new = fmaxf(m, tm);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = (m == -INFINITY) ? 0.f : __expf(m - m_use);
+    float p[8];
+    float rs = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      p[j] = (s[j] == -INFINITY) ? 0.f : __expf(s[j] - m_use);
+      rs += p[j];
+    }
+    rs += __shfl_xor(rs, 16, 64);
+    rs += __shfl_xor(rs, 32, 64);
+    l = l * alpha + rs;
+    m = m_new;
+    bf16x8 pf;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pf[j] = (__bf16)p[j];
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) {
+      o[dt] *= alpha;
+      const int key_a = 4 * g + (r16 >> 2);
+      const int within = 8 * (r16 & 3);
+      const char* p0 = sV + key_a * ROWB + ((dt ^ fV<HD>(key_a)) << 5) + within;
+      const char* p1 = sV + (key_a + 16) * ROWB + ((dt ^ fV<HD>(key_a + 16)) << 5) + within;
+      const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p0);
+      const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p1);
+      const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+    }
+  }
+
+  if (qrow < a.Sq) {
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    bf16_t* op = a.O + (size_t)b * a.o_bs + (size_t)h * a.o_hs + (size_t)qrow * a.o_ts;
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) {
+      u32x2 st = {pack2(o[dt][0] * inv, o[dt][1] * inv), pack2(o[dt][2] * inv, o[dt][3] * inv)};
+      *(u32x2*)(op + dt * 16 + 4 * g) = st;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ decode
+__device__ __forceinline__ float rescale(float m_old, float m_new) {
+  return (m_old == -INFINITY) ? 0.f : __expf(m_old - m_new);
+}
+
+// grid (H, B, DECODE_NSPLIT), 256 threads. Lane layout: 16 lanes per key (8 head-dim elements each),
+// 4 keys per wave-instruction = one contiguous 1 KiB read of the cache.
+__global__ __launch_bounds__(256) void decode_attn_kernel(DecodeAttnArgs a) {
+  __shared__ float sh_m[4], sh_l[4];
+  __shared__ __attribute__((aligned(16))) float sh_acc[4][128];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int kq = lane >> 4, c = lane & 15;
+  const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
+  const int len = *a.cur_len;
+  const int kb = a.kbeg[b];
+  const int n = len - kb;
+  const int per = (n + DECODE_NSPLIT - 1) / DECODE_NSPLIT;
+  const int k_lo = kb + sp * per;
+  const int k_hi = (k_lo + per < len) ? k_lo + per : len;
+
+  float q[8];
+  {
+    const u32x4 qv = *(const u32x4*)(a.Q + (size_t)b * a.q_bs + h * 128 + c * 8);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { q[2 * j] = lo_bf(qv[j]); q[2 * j + 1] = hi_bf(qv[j]); }
+  }
+  const bf16_t* kc = a.Kc + (size_t)b * a.c_bs + (size_t)h * a.c_hs + c * 8;
+  const bf16_t* vc = a.Vc + (size_t)b * a.c_bs + (size_t)h * a.c_hs + c * 8;
+
+  float m = -INFINITY, l = 0.f, acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+
+  constexpr int U = 4;
+  for (int base = k_lo + w * 4; base < k_hi; base += 16 * U) {
+    u32x4 kv[U], vv[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int key = base + u * 16 + kq;
+      ok[u] = key < k_hi;
+      const int kc_ = ok[u] ? key : (k_hi - 1 > 0 ? k_hi - 1 : 0);
+      kv[u] = __builtin_nontemporal_load((const u32x4*)(kc + (size_t)kc_ * 128));
+      vv[u] = __builtin_nontemporal_load((const u32x4*)(vc + (size_t)kc_ * 128));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float d = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d += q[2 * j] * lo_bf(kv[u][j]) + q[2 * j + 1] * hi_bf(kv[u][j]);
+      d += __shfl_xor(d, 1, 64);
+      d += __shfl_xor(d, 2, 64);
+      d += __shfl_xor(d, 4, 64);
+      d += __shfl_xor(d, 8, 64);
+      const float s = ok[u] ? rbf(rbf(d) * a.scale) : -INFINITY;
+      const float m_new = fmaxf(m, s);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = rescale(m, m_use);
+      const float p = (s == -INFINITY) ? 0.f : __expf(s - m_use);
+      const float pb = rbf(p);
+      l = l * alpha + p;
+      m = m_new;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[2 * j] = acc[2 * j] * alpha + pb * lo_bf(vv[u][j]);
+        acc[2 * j + 1] = acc[2 * j + 1] * alpha + pb * hi_bf(vv[u][j]);
+      }
+    }
+  }
+  // merge the 4 key slots of the wave
+#pragma unroll
+  for (int off = 16; off <= 32; off <<= 1) {
+    const float m_o = __shfl_xor(m, off, 64);
+    const float l_o = __shfl_xor(l, off, 64);
+    const float m_n = fmaxf(m, m_o);
+    const float m_use = (m_n == -INFINITY) ? 0.f : m_n;
+    const float a0 = rescale(m, m_use), a1 = rescale(m_o, m_use);
+    l = l * a0 + l_o * a1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = acc[j] * a0 + __shfl_xor(acc[j], off, 64) * a1;
+    m = m_n;
+  }
+  if (kq == 0) {
+    if (c == 0) { sh_m[w] = m; sh_l[w] = l; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sh_acc[w][c * 8 + j] = acc[j];
+  }
+  __syncthreads();
+  if (tid < 128) {
+    float mm = fmaxf(fmaxf(sh_m[0], sh_m[1]), fmaxf(sh_m[2], sh_m[3]));
+    const float m_use = (mm == -INFINITY) ? 0.f : mm;
+    float ll = 0.f, av = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float sc = rescale(sh_m[i], m_use);
+      ll += sh_l[i] * sc;
+      av += sh_acc[i][tid] * sc;
+    }
+    float* pp = a.part + (((size_t)b * a.H + h) * DECODE_NSPLIT + sp) * 130;
+    if (tid == 0) { pp[0] = mm; pp[1] = ll; }
+    pp[2 + tid] = av;
+  }
+}
+
+__global__ __launch_bounds__(128) void decode_attn_combine_kernel(DecodeAttnArgs a) {
+  const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const float* pp = a.part + ((size_t)b * a.H + h) * DECODE_NSPLIT * 130;
+  float mm = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < DECODE_NSPLIT; ++i) mm = fmaxf(mm, pp[i * 130]);
+  const float m_use = (mm == -INFINITY) ? 0.f : mm;
+  float ll = 0.f, av = 0.f;
+#pragma unroll
+  for (int i = 0; i < DECODE_NSPLIT; ++i) {
+    const float sc = rescale(pp[i * 130], m_use);
+    ll += pp[i * 130 + 1] * sc;
+    av += pp[i * 130 + 2 + tid] * sc;
+  }
+  a.O[(size_t)b * a.o_bs + h * 128 + tid] = f2bf(ll > 0.f ? av / ll : 0.f);
+}
+
+}  // namespace
+
+hipError_t launch_attention(const AttnArgs& a, int head_dim, hipStream_t s) {
+  if (a.B <= 0 || a.Sq <= 0 || a.Sk <= 0) return hipSuccess;
+  dim3 grid((a.Sq + 63) / 64, a.H, a.B);
+  if (head_dim == 128)
+    hipLaunchKernelGGL(attn_kernel<128>, grid, dim3(256), 0, s, a);
+  else if (head_dim == 64)
+    hipLaunchKernelGGL(attn_kernel<64>, grid, dim3(256), 0, s, a);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+hipError_t launch_decode_attention(const DecodeAttnArgs& a, hipStream_t s) {
+  if (a.B <= 0) return hipSuccess;
+  hipLaunchKernelGGL(decode_attn_kernel, dim3(a.H, a.B, DECODE_NSPLIT), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(decode_attn_combine_kernel, dim3(a.H, a.B), dim3(128), 0, s, a);
+  return hipGetLastError();
+}

@@ -1,0 +1,763 @@
+// C ABI (include/oracle_hip.h) + stage orchestration: weights resident in packed form, KV cache and
+// workspace pre-allocated, every stage a short sequence of the kernels in gemm/gemv/attn/norm/misc.hip.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/oracle_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+static thread_local char g_err[512] = "";
+extern "C" const char* orc_last_error(void) { return g_err; }
+extern "C" int orc_abi_version(void) { return 1; }
+
+static int fail(const char* what, const char* detail) {
+  snprintf(g_err, sizeof(g_err), "%s: %s", what, detail);
+  return -1;
+}
+#define HIPCHK(expr)                                                   \
+  do {                                                                 \
+    hipError_t _e = (expr);                                            \
+    if (_e != hipSuccess) return fail(#expr, hipGetErrorString(_e));   \
+  } while (0)
+#define ORCCHK(expr)               \
+  do {                             \
+    int _r = (expr);               \
+    if (_r != 0) return _r;        \
+  } while (0)
+
+namespace {
+
+struct Raw {
+  bf16_t* p = nullptr;
+  std::vector<int64_t> shape;
+  size_t numel = 0;
+};
+struct Packed {
+  bf16_t* p = nullptr;
+  int N = 0, K = 0, Nvalid = 0;   // padded rows / cols, valid rows
+};
+struct ClipLayer {
+  bf16_t *ln1w, *ln1b, *ln2w, *ln2b, *bqkv, *bo, *b1, *b2;
+  Packed qkv, o, fc1, fc2;
+};
+struct PoolLayer {
+  bf16_t *bqkv, *bo, *ln1w, *ln1b, *bi, *bout, *ln2w, *ln2b;
+  Packed qkv, o, wi, wout;
+};
+struct LlamaLayer {
+  bf16_t *ln_in, *ln_post;
+  Packed qkv, o, gu, down;
+};
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+}  // namespace
+
+struct orc_engine {
+  orc_config c;
+  bool finalized = false;
+  std::map<std::string, Raw> raw;
+  std::vector<void*> owned;   // device allocations freed at destroy
+
+  // CLIP
+  Packed patch_w;
+  bf16_t *clip_cls = nullptr, *clip_pos = nullptr, *pre_lnw = nullptr, *pre_lnb = nullptr, *post_lnw = nullptr, *post_lnb = nullptr;
+  std::vector<ClipLayer> clip;
+  // pooler
+  bf16_t *pool_tt0 = nullptr, *pool_pos = nullptr, *pool_elnw = nullptr, *pool_elnb = nullptr;
+  std::vector<PoolLayer> pool;
+  // projector
+  Packed proj0, proj2;
+  bf16_t *proj_b0 = nullptr, *proj_b2 = nullptr;
+  // llama
+  bf16_t* embed = nullptr;
+  std::vector<LlamaLayer> llama;
+  bf16_t* final_norm = nullptr;
+  Packed lm_head;
+  bf16_t *cos_tab = nullptr, *sin_tab = nullptr;
+  int maxpos = 0;
+
+  // KV cache: per layer K and V, [B][H][Tmax][128]
+  bf16_t *kcache = nullptr, *vcache = nullptr;
+  size_t kv_layer_elems = 0;
+  long c_bs = 0, c_hs = 0;
+
+  // workspace
+  int ws_rows = 0;
+  bf16_t *w_h = nullptr, *w_xn = nullptr, *w_qkv = nullptr, *w_att = nullptr, *w_mlp = nullptr, *w_aux = nullptr;
+  float* w_logits = nullptr;
+  float* w_part = nullptr;
+  bf16_t *d_h = nullptr, *d_xn = nullptr, *d_qkv = nullptr, *d_att = nullptr, *d_mlp = nullptr;   // decode (<=16 rows)
+  int *dev_ints = nullptr;   // [0]=step [1]=cur_len [2]=n_unfinished, then per-row arrays
+  int *d_step, *d_curlen, *d_nunf, *d_unf, *d_next, *d_argmax, *d_kbeg, *d_kend, *d_rowoff, *d_rowvalid, *d_tokens;
+  int* h_pinned = nullptr;   // pinned host staging (small int arrays)
+  int cur_batch = 0, cur_T = 0;
+
+  int alloc(void** p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+    if (e != hipSuccess) return fail("hipMalloc", hipGetErrorString(e));
+    owned.push_back(*p);
+    return 0;
+  }
+};
+
+namespace {
+
+int get_raw(orc_engine* e, const std::string& name, Raw** out, bool required = true) {
+  auto it = e->raw.find(name);
+  if (it == e->raw.end()) {
+    *out = nullptr;
+    if (required) return fail("missing weight", name.c_str());
+    return 0;
+  }
+  *out = &it->second;
+  return 0;
+}
+
+// take ownership of a raw tensor as-is (1-D params, embeddings)
+int take(orc_engine* e, const std::string& name, bf16_t** dst, size_t expect_numel) {
+  Raw* r;
+  ORCCHK(get_raw(e, name, &r));
+  if (r->numel != expect_numel) return fail("bad weight size", name.c_str());
+  *dst = r->p;
+  r->p = nullptr;   // ownership stays in e->owned
+  return 0;
+}
+
+// concatenate row-major matrices along rows into a temp, pack, free the temp
+int pack_rows(orc_engine* e, const std::vector<std::string>& names, int K, const std::vector<int>* rowmap_host, int align_n,
+              Packed* out) {
+  int nsrc = 0;
+  std::vector<Raw*> rs;
+  for (auto& n : names) {
+    Raw* r;
+    ORCCHK(get_raw(e, n, &r));
+    if (r->shape.size() < 2) return fail("weight is not a matrix", n.c_str());
+    int64_t cols = 1;
+    for (size_t i = 1; i < r->shape.size(); ++i) cols *= r->shape[i];
+    if (cols != K) return fail("bad weight inner size", n.c_str());
+    nsrc += (int)r->shape[0];
+    rs.push_back(r);
+  }
+  bf16_t* tmp = nullptr;
+  const bf16_t* src = rs[0]->p;
+  if (rs.size() > 1) {
+    HIPCHK(hipMalloc((void**)&tmp, (size_t)nsrc * K * 2));
+    size_t off = 0;
+    for (auto* r : rs) {
+      HIPCHK(hipMemcpy(tmp + off, r->p, r->numel * 2, hipMemcpyDeviceToDevice));
+      off += r->numel;
+    }
+    src = tmp;
+  }
+  const int nrows = rowmap_host ? (int)rowmap_host->size() : nsrc;
+  const int Np = round_up(nrows, align_n), Kp = round_up(K, 64);
+  int* rm = nullptr;
+  if (rowmap_host) {
+    std::vector<int> full(Np, -1);
+    memcpy(full.data(), rowmap_host->data(), rowmap_host->size() * sizeof(int));
+    HIPCHK(hipMalloc((void**)&rm, Np * sizeof(int)));
+    HIPCHK(hipMemcpy(rm, full.data(), Np * sizeof(int), hipMemcpyHostToDevice));
+  }
+  bf16_t* wp;
+  ORCCHK(e->alloc((void**)&wp, (size_t)Np * Kp * 2));
+  HIPCHK(launch_pack_weight(src, nsrc, K, rm, wp, Np, Kp, 0));
+  HIPCHK(hipDeviceSynchronize());
+  if (tmp) HIPCHK(hipFree(tmp));
+  if (rm) HIPCHK(hipFree(rm));
+  out->p = wp; out->N = Np; out->K = Kp; out->Nvalid = nrows;
+  return 0;
+}
+
+int concat_vec(orc_engine* e, const std::vector<std::string>& names, bf16_t** dst, int pad_to) {
+  size_t tot = 0;
+  std::vector<Raw*> rs;
+  for (auto& n : names) {
+    Raw* r;
+    ORCCHK(get_raw(e, n, &r));
+    rs.push_back(r);
+    tot += r->numel;
+  }
+  size_t padded = round_up((int)tot, pad_to);
+  ORCCHK(e->alloc((void**)dst, padded * 2));
+  HIPCHK(hipMemset(*dst, 0, padded * 2));
+  size_t off = 0;
+  for (auto* r : rs) {
+    HIPCHK(hipMemcpy(*dst + off, r->p, r->numel * 2, hipMemcpyDeviceToDevice));
+    off += r->numel;
+  }
+  return 0;
+}
+
+void free_raw(orc_engine* e, const std::vector<std::string>& names) {
+  for (auto& n : names) {
+    auto it = e->raw.find(n);
+    if (it == e->raw.end() || !it->second.p) continue;
+    void* p = it->second.p;
+    for (auto& o : e->owned)
+      if (o == p) { o = nullptr; break; }
+    (void)hipFree(p);
+    it->second.p = nullptr;
+  }
+}
+
+inline hipStream_t S(void* s) { return (hipStream_t)s; }
+
+int gemm(const bf16_t* X, int ldx, const Packed& W, const bf16_t* bias, const bf16_t* R, int ldr, void* C, int ldc, int M,
+         int epi, hipStream_t s, bool small) {
+  GemmArgs a;
+  a.X = X; a.ldx = ldx; a.Wp = W.p; a.bias = bias; a.R = R; a.ldr = ldr; a.C = C; a.ldc = ldc;
+  a.M = M; a.N = W.N; a.K = W.K;
+  a.Nvalid = (epi == EPI_SWIGLU) ? W.Nvalid / 2 : W.Nvalid;
+  hipError_t err = small ? launch_gemv(a, epi, s) : launch_gemm(a, epi, s);
+  if (err != hipSuccess) return fail(small ? "launch_gemv" : "launch_gemm", hipGetErrorString(err));
+  return 0;
+}
+
+}  // namespace
+
+// ============================================================================ lifecycle
+extern "C" int orc_engine_create(const orc_config* cfg, orc_engine** out) {
+  if (!cfg || !out) return fail("orc_engine_create", "null argument");
+  const orc_config& c = *cfg;
+  if (c.n_heads <= 0 || c.d_model != c.n_heads * 128) return fail("orc_engine_create", "LLaMA head_dim must be 128");
+  if (c.clip_d % c.clip_heads || c.clip_d / c.clip_heads != 64) return fail("orc_engine_create", "CLIP head_dim must be 64");
+  if (c.clip_d / c.pool_heads != 128) return fail("orc_engine_create", "pooler head_dim must be 128");
+  if (c.max_batch < 1 || c.max_batch > 16) return fail("orc_engine_create", "max_batch must be in 1..16");
+  if (c.d_model % 128 || c.d_ff % 64 || c.vocab % 128 || c.clip_d % 128 || c.clip_ff % 128 || c.pool_ff % 128)
+    return fail("orc_engine_create", "widths must be multiples of 128 (d_ff: 64)");
+  if (c.clip_image % c.clip_patch) return fail("orc_engine_create", "image size not a multiple of the patch size");
+  orc_engine* e = new orc_engine();
+  e->c = c;
+  *out = e;
+  return 0;
+}
+
+extern "C" void orc_engine_destroy(orc_engine* e) {
+  if (!e) return;
+  (void)hipDeviceSynchronize();
+  for (void* p : e->owned)
+    if (p) (void)hipFree(p);
+  if (e->h_pinned) (void)hipHostFree(e->h_pinned);
+  delete e;
+}
+
+extern "C" int orc_engine_load_weight(orc_engine* e, const char* name, const void* data, int on_device,
+                                      const int64_t* shape, int ndim) {
+  if (!e || !name || !data || !shape || ndim < 1) return fail("orc_engine_load_weight", "bad argument");
+  if (e->finalized) return fail("orc_engine_load_weight", "engine already finalized");
+  Raw r;
+  r.numel = 1;
+  for (int i = 0; i < ndim; ++i) {
+    r.shape.push_back(shape[i]);
+    r.numel *= (size_t)shape[i];
+  }
+  ORCCHK(e->alloc((void**)&r.p, r.numel * 2));
+  HIPCHK(hipMemcpy(r.p, data, r.numel * 2, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  auto old = e->raw.find(name);
+  if (old != e->raw.end()) free_raw(e, {name});
+  e->raw[name] = r;
+  return 0;
+}
+
+extern "C" int orc_engine_finalize(orc_engine* e) {
+  if (!e) return fail("orc_engine_finalize", "null engine");
+  if (e->finalized) return 0;
+  const orc_config& c = e->c;
+  char buf[256];
+  // ---------------- CLIP
+  {
+    const std::string p = "model.vision_tower.vision_tower.vision_model.";
+    const int kpatch = 3 * c.clip_patch * c.clip_patch;
+    ORCCHK(pack_rows(e, {p + "embeddings.patch_embedding.weight"}, kpatch, nullptr, 128, &e->patch_w));
+    free_raw(e, {p + "embeddings.patch_embedding.weight"});
+    const int tokens = (c.clip_image / c.clip_patch) * (c.clip_image / c.clip_patch) + 1;
+    ORCCHK(take(e, p + "embeddings.class_embedding", &e->clip_cls, c.clip_d));
+    ORCCHK(take(e, p + "embeddings.position_embedding.weight", &e->clip_pos, (size_t)tokens * c.clip_d));
+    ORCCHK(take(e, p + "pre_layrnorm.weight", &e->pre_lnw, c.clip_d));
+    ORCCHK(take(e, p + "pre_layrnorm.bias", &e->pre_lnb, c.clip_d));
+    ORCCHK(take(e, p + "post_layernorm.weight", &e->post_lnw, c.clip_d));
+    ORCCHK(take(e, p + "post_layernorm.bias", &e->post_lnb, c.clip_d));
+    e->clip.resize(c.clip_layers);
+    for (int i = 0; i < c.clip_layers; ++i) {
+      snprintf(buf, sizeof(buf), "%sencoder.layers.%d.", p.c_str(), i);
+      const std::string q = buf;
+      ClipLayer& L = e->clip[i];
+      ORCCHK(take(e, q + "layer_norm1.weight", &L.ln1w, c.clip_d));
+      ORCCHK(take(e, q + "layer_norm1.bias", &L.ln1b, c.clip_d));
+      ORCCHK(take(e, q + "layer_norm2.weight", &L.ln2w, c.clip_d));
+      ORCCHK(take(e, q + "layer_norm2.bias", &L.ln2b, c.clip_d));
+      std::vector<std::string> w3 = {q + "self_attn.q_proj.weight", q + "self_attn.k_proj.weight", q + "self_attn.v_proj.weight"};
+      ORCCHK(pack_rows(e, w3, c.clip_d, nullptr, 128, &L.qkv));
+      ORCCHK(concat_vec(e, {q + "self_attn.q_proj.bias", q + "self_attn.k_proj.bias", q + "self_attn.v_proj.bias"}, &L.bqkv, 128));
+      ORCCHK(pack_rows(e, {q + "self_attn.out_proj.weight"}, c.clip_d, nullptr, 128, &L.o));
+      ORCCHK(take(e, q + "self_attn.out_proj.bias", &L.bo, c.clip_d));
+      ORCCHK(pack_rows(e, {q + "mlp.fc1.weight"}, c.clip_d, nullptr, 128, &L.fc1));
+      ORCCHK(take(e, q + "mlp.fc1.bias", &L.b1, c.clip_ff));
+      ORCCHK(pack_rows(e, {q + "mlp.fc2.weight"}, c.clip_ff, nullptr, 128, &L.fc2));
+      ORCCHK(take(e, q + "mlp.fc2.bias", &L.b2, c.clip_d));
+      w3.push_back(q + "self_attn.out_proj.weight");
+      w3.push_back(q + "mlp.fc1.weight");
+      w3.push_back(q + "mlp.fc2.weight");
+      w3.push_back(q + "self_attn.q_proj.bias");
+      w3.push_back(q + "self_attn.k_proj.bias");
+      w3.push_back(q + "self_attn.v_proj.bias");
+      free_raw(e, w3);
+    }
+  }
+  // ---------------- pooler
+  {
+    const std::string p = "model.image_pooler.bert.";
+    Raw* r;
+    ORCCHK(get_raw(e, p + "embeddings.token_type_embeddings.weight", &r));
+    if (r->numel < (size_t)c.clip_d) return fail("bad weight size", "token_type_embeddings");
+    e->pool_tt0 = r->p;   // row 0
+    r->p = nullptr;
+    ORCCHK(take(e, p + "embeddings.position_embeddings.weight", &e->pool_pos, (size_t)c.pool_maxpos * c.clip_d));
+    ORCCHK(take(e, p + "embeddings.LayerNorm.weight", &e->pool_elnw, c.clip_d));
+    ORCCHK(take(e, p + "embeddings.LayerNorm.bias", &e->pool_elnb, c.clip_d));
+    e->pool.resize(c.pool_layers);
+    for (int i = 0; i < c.pool_layers; ++i) {
+      snprintf(buf, sizeof(buf), "%sencoder.layer.%d.", p.c_str(), i);
+      const std::string q = buf;
+      PoolLayer& L = e->pool[i];
+      std::vector<std::string> w3 = {q + "attention.self.query.weight", q + "attention.self.key.weight", q + "attention.self.value.weight"};
+      ORCCHK(pack_rows(e, w3, c.clip_d, nullptr, 128, &L.qkv));
+      ORCCHK(concat_vec(e, {q + "attention.self.query.bias", q + "attention.self.key.bias", q + "attention.self.value.bias"}, &L.bqkv, 128));
+      ORCCHK(pack_rows(e, {q + "attention.output.dense.weight"}, c.clip_d, nullptr, 128, &L.o));
+      ORCCHK(take(e, q + "attention.output.dense.bias", &L.bo, c.clip_d));
+      ORCCHK(take(e, q + "attention.output.LayerNorm.weight", &L.ln1w, c.clip_d));
+      ORCCHK(take(e, q + "attention.output.LayerNorm.bias", &L.ln1b, c.clip_d));
+      ORCCHK(pack_rows(e, {q + "intermediate.dense.weight"}, c.clip_d, nullptr, 128, &L.wi));
+      ORCCHK(take(e, q + "intermediate.dense.bias", &L.bi, c.pool_ff));
+      ORCCHK(pack_rows(e, {q + "output.dense.weight"}, c.pool_ff, nullptr, 128, &L.wout));
+      ORCCHK(take(e, q + "output.dense.bias", &L.bout, c.clip_d));
+      ORCCHK(take(e, q + "output.LayerNorm.weight", &L.ln2w, c.clip_d));
+      ORCCHK(take(e, q + "output.LayerNorm.bias", &L.ln2b, c.clip_d));
+      w3.push_back(q + "attention.output.dense.weight");
+      w3.push_back(q + "intermediate.dense.weight");
+      w3.push_back(q + "output.dense.weight");
+      w3.push_back(q + "attention.self.query.bias");
+      w3.push_back(q + "attention.self.key.bias");
+      w3.push_back(q + "attention.self.value.bias");
+      free_raw(e, w3);
+    }
+  }
+  // ---------------- projector
+  ORCCHK(pack_rows(e, {"model.mm_projector.0.weight"}, c.clip_d, nullptr, 128, &e->proj0));
+  ORCCHK(take(e, "model.mm_projector.0.bias", &e->proj_b0, c.d_model));
+  ORCCHK(pack_rows(e, {"model.mm_projector.2.weight"}, c.d_model, nullptr, 128, &e->proj2));
+  ORCCHK(take(e, "model.mm_projector.2.bias", &e->proj_b2, c.d_model));
+  free_raw(e, {"model.mm_projector.0.weight", "model.mm_projector.2.weight"});
+  // ---------------- LLaMA
+  ORCCHK(take(e, "model.embed_tokens.weight", &e->embed, (size_t)c.vocab * c.d_model));
+  ORCCHK(take(e, "model.norm.weight", &e->final_norm, c.d_model));
+  ORCCHK(pack_rows(e, {"lm_head.weight"}, c.d_model, nullptr, 128, &e->lm_head));
+  free_raw(e, {"lm_head.weight"});
+  e->llama.resize(c.n_layers);
+  std::vector<int> gu_map(2 * c.d_ff);
+  for (int pr = 0; pr < 2 * c.d_ff; ++pr) {
+    const int t = pr / 32, wi = pr % 32;   // gate tile, up tile alternate every 16 rows
+    gu_map[pr] = wi < 16 ? 16 * t + wi : c.d_ff + 16 * t + (wi - 16);
+  }
+  for (int i = 0; i < c.n_layers; ++i) {
+    snprintf(buf, sizeof(buf), "model.layers.%d.", i);
+    const std::string q = buf;
+    LlamaLayer& L = e->llama[i];
+    ORCCHK(take(e, q + "input_layernorm.weight", &L.ln_in, c.d_model));
+    ORCCHK(take(e, q + "post_attention_layernorm.weight", &L.ln_post, c.d_model));
+    std::vector<std::string> w3 = {q + "self_attn.q_proj.weight", q + "self_attn.k_proj.weight", q + "self_attn.v_proj.weight"};
+    ORCCHK(pack_rows(e, w3, c.d_model, nullptr, 128, &L.qkv));
+    ORCCHK(pack_rows(e, {q + "self_attn.o_proj.weight"}, c.d_model, nullptr, 128, &L.o));
+    std::vector<std::string> w2 = {q + "mlp.gate_proj.weight", q + "mlp.up_proj.weight"};
+    ORCCHK(pack_rows(e, w2, c.d_model, &gu_map, 128, &L.gu));
+    ORCCHK(pack_rows(e, {q + "mlp.down_proj.weight"}, c.d_ff, nullptr, 128, &L.down));
+    w3.push_back(q + "self_attn.o_proj.weight");
+    w3.push_back(w2[0]);
+    w3.push_back(w2[1]);
+    w3.push_back(q + "mlp.down_proj.weight");
+    free_raw(e, w3);
+  }
+  // ---------------- rotary tables: cos/sin(fp32 angle) rounded to bf16 (transformers LlamaRotaryEmbedding)
+  {
+    e->maxpos = c.max_seq + 8;
+    std::vector<bf16_t> ct((size_t)e->maxpos * 64), st((size_t)e->maxpos * 64);
+    for (int i = 0; i < 64; ++i) {
+      const float expo = (float)(2 * i) / 128.0f;
+      const float inv = 1.0f / powf(c.rope_theta, expo);
+      for (int p = 0; p < e->maxpos; ++p) {
+        const float ang = inv * (float)p;
+        const float cf = (float)cos((double)ang), sf = (float)sin((double)ang);
+        uint32_t u;
+        memcpy(&u, &cf, 4);
+        ct[(size_t)p * 64 + i] = (bf16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+        memcpy(&u, &sf, 4);
+        st[(size_t)p * 64 + i] = (bf16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+      }
+    }
+    ORCCHK(e->alloc((void**)&e->cos_tab, ct.size() * 2));
+    ORCCHK(e->alloc((void**)&e->sin_tab, st.size() * 2));
+    HIPCHK(hipMemcpy(e->cos_tab, ct.data(), ct.size() * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->sin_tab, st.data(), st.size() * 2, hipMemcpyHostToDevice));
+  }
+  // ---------------- KV cache + workspace
+  {
+    e->c_hs = (long)c.max_seq * 128;
+    e->c_bs = e->c_hs * c.n_heads;
+    e->kv_layer_elems = (size_t)e->c_bs * c.max_batch;
+    ORCCHK(e->alloc((void**)&e->kcache, e->kv_layer_elems * c.n_layers * 2));
+    ORCCHK(e->alloc((void**)&e->vcache, e->kv_layer_elems * c.n_layers * 2));
+    const int tokens = (c.clip_image / c.clip_patch) * (c.clip_image / c.clip_patch) + 1;
+    int rows = c.max_images * tokens;
+    if (c.max_batch * c.max_seq > rows) rows = c.max_batch * c.max_seq;
+    if (c.max_batch * c.pool_maxpos > rows) rows = c.max_batch * c.pool_maxpos;
+    rows = round_up(rows, 128);
+    e->ws_rows = rows;
+    const int wd = c.d_model > c.clip_d ? c.d_model : c.clip_d;
+    int wm = c.d_ff;
+    if (c.clip_ff > wm) wm = c.clip_ff;
+    if (c.pool_ff > wm) wm = c.pool_ff;
+    if (c.d_model > wm) wm = c.d_model;
+    ORCCHK(e->alloc((void**)&e->w_h, (size_t)rows * wd * 2));
+    ORCCHK(e->alloc((void**)&e->w_xn, (size_t)rows * wd * 2));
+    ORCCHK(e->alloc((void**)&e->w_att, (size_t)rows * wd * 2));
+    ORCCHK(e->alloc((void**)&e->w_aux, (size_t)rows * wd * 2));
+    ORCCHK(e->alloc((void**)&e->w_qkv, (size_t)rows * wd * 3 * 2));
+    ORCCHK(e->alloc((void**)&e->w_mlp, (size_t)rows * wm * 2));
+    ORCCHK(e->alloc((void**)&e->w_logits, (size_t)16 * c.vocab * 4));
+    ORCCHK(e->alloc((void**)&e->w_part, (size_t)16 * c.n_heads * DECODE_NSPLIT * 130 * 4));
+    ORCCHK(e->alloc((void**)&e->d_h, (size_t)16 * c.d_model * 2));
+    ORCCHK(e->alloc((void**)&e->d_xn, (size_t)16 * c.d_model * 2));
+    ORCCHK(e->alloc((void**)&e->d_att, (size_t)16 * c.d_model * 2));
+    ORCCHK(e->alloc((void**)&e->d_qkv, (size_t)16 * c.d_model * 3 * 2));
+    ORCCHK(e->alloc((void**)&e->d_mlp, (size_t)16 * c.d_ff * 2));
+    const size_t nint = 16 + 16 * 8 + (size_t)16 * c.max_new_tokens;
+    ORCCHK(e->alloc((void**)&e->dev_ints, nint * 4));
+    HIPCHK(hipMemset(e->dev_ints, 0, nint * 4));
+    e->d_step = e->dev_ints;
+    e->d_curlen = e->dev_ints + 1;
+    e->d_nunf = e->dev_ints + 2;
+    int* base = e->dev_ints + 16;
+    e->d_unf = base; e->d_next = base + 16; e->d_argmax = base + 32; e->d_kbeg = base + 48;
+    e->d_kend = base + 64; e->d_rowoff = base + 80; e->d_rowvalid = base + 96;
+    e->d_tokens = base + 128;
+    HIPCHK(hipHostMalloc((void**)&e->h_pinned, 4096, hipHostMallocDefault));
+  }
+  HIPCHK(hipDeviceSynchronize());
+  e->finalized = true;
+  return 0;
+}
+
+// ============================================================================ vision
+static int clip_forward(orc_engine* e, const void* images, int n, int n_layers, hipStream_t s) {
+  const orc_config& c = e->c;
+  const int G = c.clip_image / c.clip_patch, patches = G * G, tokens = patches + 1, d = c.clip_d;
+  if (n <= 0 || n > c.max_images) return fail("vision", "n_images outside 1..max_images");
+  const int Mp = n * patches, M = n * tokens;
+  // patch embedding as GEMM: im2col -> [Mp][Kp] x W[d][Kp]
+  HIPCHK(launch_im2col((const bf16_t*)images, n, c.clip_image, c.clip_patch, e->w_mlp, e->patch_w.K, s));
+  ORCCHK(gemm(e->w_mlp, e->patch_w.K, e->patch_w, nullptr, nullptr, 0, e->w_xn, d, Mp, EPI_NONE, s, false));
+  HIPCHK(launch_clip_embed(e->w_xn, e->clip_cls, e->clip_pos, nullptr, nullptr, e->w_h, n, tokens, d, 0.f, s));
+  HIPCHK(launch_layernorm(e->w_h, d, e->pre_lnw, e->pre_lnb, e->w_h, d, M, d, c.clip_eps, s));
+  for (int i = 0; i < n_layers; ++i) {
+    const ClipLayer& L = e->clip[i];
+    HIPCHK(launch_layernorm(e->w_h, d, L.ln1w, L.ln1b, e->w_xn, d, M, d, c.clip_eps, s));
+    ORCCHK(gemm(e->w_xn, d, L.qkv, L.bqkv, nullptr, 0, e->w_qkv, 3 * d, M, EPI_NONE, s, false));
+    AttnArgs a;
+    a.Q = e->w_qkv; a.K = e->w_qkv + d; a.V = e->w_qkv + 2 * d;
+    a.q_bs = a.k_bs = a.v_bs = (long)tokens * 3 * d; a.q_hs = a.k_hs = a.v_hs = 64; a.q_ts = a.k_ts = a.v_ts = 3 * d;
+    a.O = e->w_att; a.o_bs = (long)tokens * d; a.o_hs = 64; a.o_ts = d;
+    a.B = n; a.H = c.clip_heads; a.Sq = tokens; a.Sk = tokens; a.kbeg = nullptr; a.kend = nullptr; a.causal = 0; a.q_off = 0;
+    a.scale = 0.125f;   // 64^-0.5
+    HIPCHK(launch_attention(a, 64, s));
+    ORCCHK(gemm(e->w_att, d, L.o, L.bo, e->w_h, d, e->w_h, d, M, EPI_RESIDUAL, s, false));
+    HIPCHK(launch_layernorm(e->w_h, d, L.ln2w, L.ln2b, e->w_xn, d, M, d, c.clip_eps, s));
+    ORCCHK(gemm(e->w_xn, d, L.fc1, L.b1, nullptr, 0, e->w_mlp, c.clip_ff, M, EPI_QUICKGELU, s, false));
+    ORCCHK(gemm(e->w_mlp, c.clip_ff, L.fc2, L.b2, e->w_h, d, e->w_h, d, M, EPI_RESIDUAL, s, false));
+  }
+  return 0;
+}
+
+extern "C" int orc_vision_encode(orc_engine* e, const void* images, int n_images, void* out, void* stream) {
+  if (!e || !e->finalized) return fail("orc_vision_encode", "engine not finalized");
+  const orc_config& c = e->c;
+  ORCCHK(clip_forward(e, images, n_images, c.clip_layers - 1, S(stream)));
+  const int G = c.clip_image / c.clip_patch;
+  HIPCHK(launch_strip_cls(e->w_h, (bf16_t*)out, n_images, G * G + 1, c.clip_d, S(stream)));
+  return 0;
+}
+
+extern "C" int orc_vision_global(orc_engine* e, const void* images, int n_images, void* out, void* stream) {
+  if (!e || !e->finalized) return fail("orc_vision_global", "engine not finalized");
+  const orc_config& c = e->c;
+  ORCCHK(clip_forward(e, images, n_images, c.clip_layers, S(stream)));
+  const int G = c.clip_image / c.clip_patch;
+  // CLS rows (stride tokens*d) -> post_layernorm
+  HIPCHK(launch_layernorm(e->w_h, (G * G + 1) * c.clip_d, e->post_lnw, e->post_lnb, (bf16_t*)out, c.clip_d, n_images,
+                          c.clip_d, c.clip_eps, S(stream)));
+  return 0;
+}
+
+extern "C" int orc_pool_views(orc_engine* e, const void* features, const int32_t* views, int B, void* out, void* stream) {
+  if (!e || !e->finalized) return fail("orc_pool_views", "engine not finalized");
+  const orc_config& c = e->c;
+  hipStream_t s = S(stream);
+  const int G = c.clip_image / c.clip_patch, patches = G * G, d = c.clip_d;
+  if (B < 1 || B > c.max_batch) return fail("orc_pool_views", "batch outside 1..max_batch");
+  int vmax = 0, off = 0;
+  int* hp = e->h_pinned;
+  HIPCHK(hipStreamSynchronize(s));   // pinned staging reuse
+  for (int b = 0; b < B; ++b) {
+    if (views[b] < 1) return fail("orc_pool_views", "a row has no views");
+    hp[b] = off * patches;
+    hp[16 + b] = views[b] * patches;
+    off += views[b];
+    if (views[b] > vmax) vmax = views[b];
+  }
+  const int Sx = vmax * patches;
+  if (Sx > c.pool_maxpos) return fail("orc_pool_views", "views*patches exceeds the pooler's max_position_embeddings");
+  if (off > c.max_images) return fail("orc_pool_views", "too many images");
+  HIPCHK(hipMemcpyAsync(e->d_rowoff, hp, 16 * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(e->d_rowvalid, hp + 16, 16 * 4, hipMemcpyHostToDevice, s));
+  const int M = B * Sx;
+  HIPCHK(launch_bert_embed((const bf16_t*)features, e->d_rowoff, e->d_rowvalid, e->pool_tt0, e->pool_pos, nullptr, nullptr,
+                           e->w_h, B, Sx, d, 0.f, s));
+  HIPCHK(launch_layernorm(e->w_h, d, e->pool_elnw, e->pool_elnb, e->w_h, d, M, d, c.pool_eps, s));
+  for (int i = 0; i < c.pool_layers; ++i) {
+    const PoolLayer& L = e->pool[i];
+    ORCCHK(gemm(e->w_h, d, L.qkv, L.bqkv, nullptr, 0, e->w_qkv, 3 * d, M, EPI_NONE, s, false));
+    AttnArgs a;
+    a.Q = e->w_qkv; a.K = e->w_qkv + d; a.V = e->w_qkv + 2 * d;
+    a.q_bs = a.k_bs = a.v_bs = (long)Sx * 3 * d; a.q_hs = a.k_hs = a.v_hs = 128; a.q_ts = a.k_ts = a.v_ts = 3 * d;
+    a.O = e->w_att; a.o_bs = (long)Sx * d; a.o_hs = 128; a.o_ts = d;
+    a.B = B; a.H = c.pool_heads; a.Sq = Sx; a.Sk = Sx; a.kbeg = nullptr; a.kend = e->d_rowvalid; a.causal = 0; a.q_off = 0;
+    a.scale = 0.08838834764831845f;   // 128^-0.5
+    HIPCHK(launch_attention(a, 128, s));
+    ORCCHK(gemm(e->w_att, d, L.o, L.bo, e->w_h, d, e->w_h, d, M, EPI_RESIDUAL, s, false));
+    HIPCHK(launch_layernorm(e->w_h, d, L.ln1w, L.ln1b, e->w_h, d, M, d, c.pool_eps, s));
+    ORCCHK(gemm(e->w_h, d, L.wi, L.bi, nullptr, 0, e->w_mlp, c.pool_ff, M, EPI_GELU, s, false));
+    ORCCHK(gemm(e->w_mlp, c.pool_ff, L.wout, L.bout, e->w_h, d, e->w_h, d, M, EPI_RESIDUAL, s, false));
+    HIPCHK(launch_layernorm(e->w_h, d, L.ln2w, L.ln2b, e->w_h, d, M, d, c.pool_eps, s));
+  }
+  HIPCHK(launch_copy_rows(e->w_h, (long)Sx * d, (bf16_t*)out, (long)patches * d, B, patches, d, s));
+  return 0;
+}
+
+extern "C" int orc_project(orc_engine* e, const void* x, int rows, void* out, void* stream) {
+  if (!e || !e->finalized) return fail("orc_project", "engine not finalized");
+  const orc_config& c = e->c;
+  if (rows < 1 || rows > e->ws_rows) return fail("orc_project", "rows outside workspace capacity");
+  ORCCHK(gemm((const bf16_t*)x, c.clip_d, e->proj0, e->proj_b0, nullptr, 0, e->w_mlp, c.d_model, rows, EPI_GELU, S(stream), false));
+  ORCCHK(gemm(e->w_mlp, c.d_model, e->proj2, e->proj_b2, nullptr, 0, out, c.d_model, rows, EPI_NONE, S(stream), false));
+  return 0;
+}
+
+extern "C" int orc_view_reduce(orc_engine* e, const void* x, int B, int V, int64_t n, int mode, void* out, void* stream) {
+  (void)e;
+  if (B < 1 || V < 1 || n < 1 || (mode != 0 && mode != 1)) return fail("orc_view_reduce", "bad argument");
+  HIPCHK(launch_view_reduce((const bf16_t*)x, (bf16_t*)out, B, V, (int)n, mode, S(stream)));
+  return 0;
+}
+
+extern "C" int orc_pool2x2(orc_engine* e, const void* x, int n_images, int grid, int d, void* out, void* stream) {
+  (void)e;
+  if (n_images < 1 || grid < 2 || (grid & 1)) return fail("orc_pool2x2", "bad argument");
+  HIPCHK(launch_pool2x2((const bf16_t*)x, (bf16_t*)out, n_images, grid, d, S(stream)));
+  return 0;
+}
+
+extern "C" int orc_splice(orc_engine* e, const int32_t* codes, int rows, const void* img, const void* desc, void* out,
+                          void* stream) {
+  if (!e || !e->finalized) return fail("orc_splice", "engine not finalized");
+  HIPCHK(launch_gather_rows(codes, e->embed, (const bf16_t*)img, (const bf16_t*)desc, (bf16_t*)out, rows, e->c.d_model, S(stream)));
+  return 0;
+}
+
+// ============================================================================ LLaMA
+static int llama_layers(orc_engine* e, bf16_t* h, bf16_t* xn, bf16_t* qkv, bf16_t* att, bf16_t* mlp, int B, int T,
+                        const int32_t* pos, bool decode, hipStream_t s) {
+  const orc_config& c = e->c;
+  const int d = c.d_model, M = B * T;
+  for (int i = 0; i < c.n_layers; ++i) {
+    const LlamaLayer& L = e->llama[i];
+    bf16_t* kc = e->kcache + (size_t)i * e->kv_layer_elems;
+    bf16_t* vc = e->vcache + (size_t)i * e->kv_layer_elems;
+    HIPCHK(launch_rmsnorm(h, d, L.ln_in, xn, d, M, d, c.rms_eps, s));
+    ORCCHK(gemm(xn, d, L.qkv, nullptr, nullptr, 0, qkv, 3 * d, M, EPI_NONE, s, decode));
+    RopeArgs r;
+    r.qkv = qkv; r.B = B; r.T = T; r.H = c.n_heads; r.pos = decode ? nullptr : pos; r.kbeg = e->d_kbeg; r.cur_len = e->d_curlen;
+    r.cos_tab = e->cos_tab; r.sin_tab = e->sin_tab; r.maxpos = e->maxpos; r.Kc = kc; r.Vc = vc; r.c_bs = e->c_bs; r.c_hs = e->c_hs;
+    r.t0 = 0;
+    HIPCHK(launch_rope_kv(r, s));
+    if (!decode) {
+      AttnArgs a;
+      a.Q = qkv; a.q_bs = (long)T * 3 * d; a.q_hs = 128; a.q_ts = 3 * d;
+      a.K = kc; a.k_bs = e->c_bs; a.k_hs = e->c_hs; a.k_ts = 128;
+      a.V = vc; a.v_bs = e->c_bs; a.v_hs = e->c_hs; a.v_ts = 128;
+      a.O = att; a.o_bs = (long)T * d; a.o_hs = 128; a.o_ts = d;
+      a.B = B; a.H = c.n_heads; a.Sq = T; a.Sk = T; a.kbeg = e->d_kbeg; a.kend = nullptr; a.causal = 1; a.q_off = 0;
+      a.scale = 0.08838834764831845f;
+      HIPCHK(launch_attention(a, 128, s));
+    } else {
+      DecodeAttnArgs a;
+      a.Q = qkv; a.q_bs = 3 * d; a.Kc = kc; a.Vc = vc; a.c_bs = e->c_bs; a.c_hs = e->c_hs; a.O = att; a.o_bs = d;
+      a.part = e->w_part; a.kbeg = e->d_kbeg; a.cur_len = e->d_curlen; a.B = B; a.H = c.n_heads;
+      a.scale = 0.08838834764831845f;
+      HIPCHK(launch_decode_attention(a, s));
+    }
+    ORCCHK(gemm(att, d, L.o, nullptr, h, d, h, d, M, EPI_RESIDUAL, s, decode));
+    HIPCHK(launch_rmsnorm(h, d, L.ln_post, xn, d, M, d, c.rms_eps, s));
+    ORCCHK(gemm(xn, d, L.gu, nullptr, nullptr, 0, mlp, c.d_ff, M, EPI_SWIGLU, s, decode));
+    ORCCHK(gemm(mlp, c.d_ff, L.down, nullptr, h, d, h, d, M, EPI_RESIDUAL, s, decode));
+  }
+  return 0;
+}
+
+static int head_and_sample(orc_engine* e, const bf16_t* hrows, int ldh, int B, float* logits_out, hipStream_t s) {
+  const orc_config& c = e->c;
+  HIPCHK(launch_rmsnorm(hrows, ldh, e->final_norm, e->d_xn, c.d_model, B, c.d_model, c.rms_eps, s));
+  ORCCHK(gemm(e->d_xn, c.d_model, e->lm_head, nullptr, nullptr, 0, e->w_logits, c.vocab, B, EPI_F32, s, true));
+  if (logits_out)
+    HIPCHK(hipMemcpyAsync(logits_out, e->w_logits, (size_t)B * c.vocab * 4, hipMemcpyDeviceToDevice, s));
+  SampleArgs a;
+  a.logits = e->w_logits; a.vocab = c.vocab; a.B = B; a.unfinished = e->d_unf; a.next_ids = e->d_next;
+  a.raw_argmax = e->d_argmax; a.out_tokens = e->d_tokens; a.out_ld = c.max_new_tokens; a.step = e->d_step;
+  a.cur_len = e->d_curlen; a.n_unfinished = e->d_nunf; a.pad_id = c.pad_token_id; a.eos_id = c.eos_token_id;
+  HIPCHK(launch_argmax_sample(a, s));
+  return 0;
+}
+
+extern "C" int orc_prefill(orc_engine* e, const void* embeds, const int32_t* position_ids, const int32_t* left_pad,
+                           int B, int T, float* logits_out, void* stream) {
+  if (!e || !e->finalized) return fail("orc_prefill", "engine not finalized");
+  const orc_config& c = e->c;
+  hipStream_t s = S(stream);
+  if (B < 1 || B > c.max_batch) return fail("orc_prefill", "batch outside 1..max_batch");
+  if (T < 1 || T >= c.max_seq) return fail("orc_prefill", "prompt length exceeds max_seq");
+  if (B * T > e->ws_rows) return fail("orc_prefill", "batch*T exceeds workspace");
+  HIPCHK(hipStreamSynchronize(s));
+  int* hp = e->h_pinned;
+  for (int i = 0; i < 64; ++i) hp[i] = 0;
+  hp[0] = 0;       // step
+  hp[1] = T;       // cur_len: keys cached after prefill; sampling advances it to T+1 for the first decode step
+  hp[2] = B;
+  for (int b = 0; b < B; ++b) {
+    if (left_pad[b] < 0 || left_pad[b] >= T) return fail("orc_prefill", "left_pad outside 0..T-1");
+    hp[16 + b] = 1;                 // unfinished
+    hp[16 + 48 + b] = left_pad[b];  // kbeg
+  }
+  HIPCHK(hipMemcpyAsync(e->dev_ints, hp, 16 * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(e->d_unf, hp + 16, 16 * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(e->d_kbeg, hp + 16 + 48, 16 * 4, hipMemcpyHostToDevice, s));
+  e->cur_batch = B;
+  e->cur_T = T;
+  const int d = c.d_model, M = B * T;
+  HIPCHK(hipMemcpyAsync(e->w_h, embeds, (size_t)M * d * 2, hipMemcpyDeviceToDevice, s));
+  ORCCHK(llama_layers(e, e->w_h, e->w_xn, e->w_qkv, e->w_att, e->w_mlp, B, T, position_ids, false, s));
+  // last position of every (left-padded) row: row b*T + T-1  -> stride T*d
+  ORCCHK(head_and_sample(e, e->w_h + (size_t)(T - 1) * d, T * d, B, logits_out, s));
+  return 0;
+}
+
+static int decode_one(orc_engine* e, const int32_t* forced, float* logits_out, hipStream_t s) {
+  const orc_config& c = e->c;
+  const int B = e->cur_batch;
+  HIPCHK(launch_embed_tokens(forced ? forced : e->d_next, e->embed, e->d_h, B, c.d_model, c.vocab, s));
+  ORCCHK(llama_layers(e, e->d_h, e->d_xn, e->d_qkv, e->d_att, e->d_mlp, B, 1, nullptr, true, s));
+  ORCCHK(head_and_sample(e, e->d_h, c.d_model, B, logits_out, s));
+  return 0;
+}
+
+extern "C" int orc_decode_step(orc_engine* e, const int32_t* forced_ids, float* logits_out, void* stream) {
+  if (!e || !e->finalized || e->cur_batch == 0) return fail("orc_decode_step", "no prefill has run");
+  return decode_one(e, forced_ids, logits_out, S(stream));
+}
+
+extern "C" int orc_decode_steps(orc_engine* e, int n_steps, void* stream) {
+  if (!e || !e->finalized || e->cur_batch == 0) return fail("orc_decode_steps", "no prefill has run");
+  for (int i = 0; i < n_steps; ++i) ORCCHK(decode_one(e, nullptr, nullptr, S(stream)));
+  return 0;
+}
+
+extern "C" int orc_read_state(orc_engine* e, int32_t* tokens_host, int32_t* steps_host, int32_t* n_unf_host,
+                              int32_t* last_argmax_host, void* stream) {
+  if (!e || !e->finalized) return fail("orc_read_state", "engine not finalized");
+  hipStream_t s = S(stream);
+  int hdr[16];
+  HIPCHK(hipMemcpyAsync(hdr, e->dev_ints, 16 * 4, hipMemcpyDeviceToHost, s));
+  if (tokens_host && e->cur_batch > 0)
+    HIPCHK(hipMemcpyAsync(tokens_host, e->d_tokens, (size_t)e->cur_batch * e->c.max_new_tokens * 4, hipMemcpyDeviceToHost, s));
+  if (last_argmax_host && e->cur_batch > 0)
+    HIPCHK(hipMemcpyAsync(last_argmax_host, e->d_argmax, (size_t)e->cur_batch * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (steps_host) *steps_host = hdr[0];
+  if (n_unf_host) *n_unf_host = hdr[2];
+  return 0;
+}
+
+extern "C" int64_t orc_decode_weight_bytes(orc_engine* e) {
+  const orc_config& c = e->c;
+  const int64_t per_layer = (int64_t)4 * c.d_model * c.d_model + (int64_t)3 * c.d_model * c.d_ff + 2 * c.d_model;
+  return 2 * (per_layer * c.n_layers + c.d_model + (int64_t)c.vocab * c.d_model);
+}
+extern "C" int64_t orc_kv_bytes_per_key(orc_engine* e) { return (int64_t)2 * 2 * e->c.n_layers * e->c.d_model; }
+
+// ============================================================================ single-kernel hooks
+extern "C" int orc_test_gemm(const void* x, int M, int K, const void* w, int N, const void* bias, const void* residual,
+                             int epi, int use_gemv, void* out, void* stream) {
+  hipStream_t s = S(stream);
+  const int Np = round_up(N, 128), Kp = round_up(K, 64);
+  if (Kp != K) return fail("orc_test_gemm", "K must be a multiple of 64");
+  bf16_t* wp;
+  HIPCHK(hipMalloc((void**)&wp, (size_t)Np * Kp * 2));
+  int* rm = nullptr;
+  if (epi == EPI_SWIGLU) {   // w = [gate(N/2 rows); up(N/2 rows)] -> interleave 16-row tiles
+    std::vector<int> m(Np, -1);
+    for (int pr = 0; pr < N; ++pr) {
+      const int t = pr / 32, wi = pr % 32;
+      m[pr] = wi < 16 ? 16 * t + wi : N / 2 + 16 * t + (wi - 16);
+    }
+    HIPCHK(hipMalloc((void**)&rm, Np * 4));
+    HIPCHK(hipMemcpy(rm, m.data(), Np * 4, hipMemcpyHostToDevice));
+  }
+  HIPCHK(launch_pack_weight((const bf16_t*)w, N, K, rm, wp, Np, Kp, s));
+  GemmArgs a;
+  a.X = (const bf16_t*)x; a.ldx = K; a.Wp = wp; a.bias = (const bf16_t*)bias; a.R = (const bf16_t*)residual;
+  const int nout = epi == EPI_SWIGLU ? N / 2 : N;
+  a.ldr = nout; a.C = out; a.ldc = nout; a.M = M; a.N = Np; a.K = Kp; a.Nvalid = nout;
+  hipError_t err = use_gemv ? launch_gemv(a, epi, s) : launch_gemm(a, epi, s);
+  if (err != hipSuccess) return fail("orc_test_gemm", hipGetErrorString(err));
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipFree(wp));
+  if (rm) HIPCHK(hipFree(rm));
+  return 0;
+}
+
+extern "C" int orc_test_rmsnorm(const void* x, const void* w, int rows, int d, float eps, void* out, void* stream) {
+  HIPCHK(launch_rmsnorm((const bf16_t*)x, d, (const bf16_t*)w, (bf16_t*)out, d, rows, d, eps, S(stream)));
+  return 0;
+}
+extern "C" int orc_test_layernorm(const void* x, const void* w, const void* b, int rows, int d, float eps, void* out,
+                                  void* stream) {
+  HIPCHK(launch_layernorm((const bf16_t*)x, d, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)out, d, rows, d, eps, S(stream)));
+  return 0;
+}
+// q,k,v,out contiguous (B, H, S, head_dim)
+extern "C" int orc_test_attention(const void* q, const void* k, const void* v, int B, int H, int Sq, int Sk, int hd,
+                                  const int32_t* kbeg, const int32_t* kend, int causal, int q_off, float scale, void* out,
+                                  void* stream) {
+  AttnArgs a;
+  a.Q = (const bf16_t*)q; a.q_bs = (long)H * Sq * hd; a.q_hs = (long)Sq * hd; a.q_ts = hd;
+  a.K = (const bf16_t*)k; a.k_bs = (long)H * Sk * hd; a.k_hs = (long)Sk * hd; a.k_ts = hd;
+  a.V = (const bf16_t*)v; a.v_bs = a.k_bs; a.v_hs = a.k_hs; a.v_ts = hd;
+  a.O = (bf16_t*)out; a.o_bs = a.q_bs; a.o_hs = a.q_hs; a.o_ts = hd;
+  a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.kbeg = kbeg; a.kend = kend; a.causal = causal; a.q_off = q_off; a.scale = scale;
+  HIPCHK(launch_attention(a, hd, S(stream)));
+  return 0;
+}

@@ -1,0 +1,104 @@
+// Internal launcher interface between the engine (engine.hip) and the kernel files. Not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "common.h"
+
+enum { EPI_NONE = 0, EPI_QUICKGELU = 1, EPI_GELU = 2, EPI_RESIDUAL = 3, EPI_SWIGLU = 4, EPI_F32 = 5 };
+
+struct GemmArgs {
+  const bf16_t* X; int ldx;   // activations [M][K] row-major
+  const bf16_t* Wp;           // packed weights, Np = N rows (multiple of 128), Kp = K (multiple of 64)
+  const bf16_t* bias;         // [N] or null
+  const bf16_t* R; int ldr;   // residual [M][N] (EPI_RESIDUAL)
+  void* C; int ldc;           // bf16 (fp32 for EPI_F32); EPI_SWIGLU writes N/2 columns
+  int M, N, K;
+  int Nvalid;                 // columns actually stored (<= N, or <= N/2 for SWIGLU)
+};
+hipError_t launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
+// decode-time skinny GEMM (M <= 16), same argument meaning; N multiple of 16 (32 for SWIGLU)
+hipError_t launch_gemv(const GemmArgs& a, int epi, hipStream_t s);
+hipError_t launch_pack_weight(const bf16_t* W, int Nsrc, int K, const int* rowmap, bf16_t* Wp, int Np, int Kp,
+                              hipStream_t s);
+
+// ---- norms
+hipError_t launch_rmsnorm(const bf16_t* x, int ldx, const bf16_t* w, bf16_t* y, int ldy, int rows, int d, float eps,
+                          hipStream_t s);
+hipError_t launch_layernorm(const bf16_t* x, int ldx, const bf16_t* w, const bf16_t* b, bf16_t* y, int ldy, int rows,
+                            int d, float eps, hipStream_t s);
+
+// ---- attention (flash style, MFMA). Generic strides in elements.
+struct AttnArgs {
+  const bf16_t* Q; long q_bs, q_hs, q_ts;   // batch / head / token strides
+  const bf16_t* K; long k_bs, k_hs, k_ts;
+  const bf16_t* V; long v_bs, v_hs, v_ts;
+  bf16_t* O; long o_bs, o_hs, o_ts;
+  int B, H, Sq, Sk;
+  const int* kbeg;   // [B] first valid key (null = 0)
+  const int* kend;   // [B] one past last valid key (null = Sk)
+  int causal;        // key j visible to query i iff j <= i + q_off
+  int q_off;
+  float scale;
+};
+hipError_t launch_attention(const AttnArgs& a, int head_dim, hipStream_t s);
+
+// ---- decode attention over the KV cache (one query token per row)
+struct DecodeAttnArgs {
+  const bf16_t* Q; long q_bs;                // [B][H*128]
+  const bf16_t* Kc; const bf16_t* Vc;        // [B][H][Tmax][128]
+  long c_bs, c_hs;
+  bf16_t* O; long o_bs;                      // [B][H*128]
+  float* part;                               // workspace [B][H][NSPLIT][2+128]
+  const int* kbeg;                           // [B] left-pad offset
+  const int* cur_len;                        // device scalar: number of cached keys incl. the new one
+  int B, H;
+  float scale;
+};
+#define DECODE_NSPLIT 4
+hipError_t launch_decode_attention(const DecodeAttnArgs& a, hipStream_t s);
+
+// ---- rotary + KV-cache write. qkv [rows][3*H*128]; row = b*T + t; q rotated in place.
+struct RopeArgs {
+  bf16_t* qkv; int B, T, H;
+  const int* pos;             // [B*T] position ids (null: decode mode, pos = *cur_len - 1 - kbeg[b])
+  const int* kbeg;            // decode mode only
+  const int* cur_len;         // decode mode: device scalar; cache slot = *cur_len - 1
+  const bf16_t* cos_tab; const bf16_t* sin_tab;   // [maxpos][64]
+  int maxpos;
+  bf16_t* Kc; bf16_t* Vc; long c_bs, c_hs;        // cache [B][H][Tmax][128]
+  int t0;                     // prefill: cache slot of token t is t0 + t
+};
+hipError_t launch_rope_kv(const RopeArgs& a, hipStream_t s);
+
+// ---- small data-movement kernels
+hipError_t launch_im2col(const bf16_t* img, int n_img, int image, int patch, bf16_t* out, int kp, hipStream_t s);
+hipError_t launch_clip_embed(const bf16_t* patches, const bf16_t* cls, const bf16_t* pos, const bf16_t* lnw,
+                             const bf16_t* lnb, bf16_t* out, int n_img, int tokens, int d, float eps, hipStream_t s);
+hipError_t launch_bert_embed(const bf16_t* feats, const int* row_off, const int* row_valid, const bf16_t* tt0,
+                             const bf16_t* pos, const bf16_t* lnw, const bf16_t* lnb, bf16_t* out, int B, int S, int d,
+                             float eps, hipStream_t s);
+hipError_t launch_strip_cls(const bf16_t* h, bf16_t* out, int n_img, int tokens, int d, hipStream_t s);
+hipError_t launch_copy_rows(const bf16_t* src, long src_bs, bf16_t* dst, long dst_bs, int B, int rows, int d,
+                            hipStream_t s);
+// splice: out[r][:] = kind==0 ? 0 : table_kind[idx][:]   (code = kind<<28 | idx)
+hipError_t launch_gather_rows(const int* codes, const bf16_t* tok, const bf16_t* img, const bf16_t* desc, bf16_t* out,
+                              int rows, int d, hipStream_t s);
+hipError_t launch_embed_tokens(const int* ids, const bf16_t* tok, bf16_t* out, int rows, int d, int vocab,
+                               hipStream_t s);
+hipError_t launch_view_reduce(const bf16_t* x, bf16_t* out, int B, int V, int n, int mode, hipStream_t s);
+hipError_t launch_pool2x2(const bf16_t* x, bf16_t* out, int n_img, int grid, int d, hipStream_t s);
+
+// ---- greedy sampling state machine (device resident)
+struct SampleArgs {
+  const float* logits; int vocab; int B;
+  int* unfinished;     // [B]
+  int* next_ids;       // [B] token fed to the next step
+  int* raw_argmax;     // [B] argmax before the finished-row substitution (may be null)
+  int* out_tokens; int out_ld;   // [B][max_new] generated tokens
+  int* step;           // device scalar, incremented
+  int* cur_len;        // device scalar, incremented (number of cached keys for the NEXT step incl. its token)
+  int* n_unfinished;   // device scalar: rows still unfinished after this step
+  int pad_id, eos_id;
+};
+hipError_t launch_argmax_sample(const SampleArgs& a, hipStream_t s);

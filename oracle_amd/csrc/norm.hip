@@ -1,0 +1,131 @@
+// RMSNorm (LLaMA) and LayerNorm (CLIP, pooler BERT): one 256-thread workgroup per row, 16-byte loads,
+// fp32 statistics by wavefront shuffle reduction + LDS across the 4 waves. HBM/L2-bound.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// y = w * bf16( x * rsqrt(mean(x^2) + eps) )   (transformers LlamaRMSNorm: stats fp32, cast, then weight)
+// d <= 8192, d % 8 == 0
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ w,
+                                                      bf16_t* __restrict__ y, int ldy, int d, float eps) {
+  __shared__ float sh[4];
+  const int row = blockIdx.x;
+  const bf16_t* xr = x + (size_t)row * ldx;
+  bf16_t* yr = y + (size_t)row * ldy;
+  const int nch = d >> 3;
+  u32x4 v[4];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = threadIdx.x + i * 256;
+    if (c < nch) {
+      v[i] = *(const u32x4*)(xr + c * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float a = lo_bf(v[i][j]), b = hi_bf(v[i][j]);
+        ss += a * a + b * b;
+      }
+    }
+  }
+  ss = block_sum(ss, sh);
+  const float r = rsqrtf(ss / (float)d + eps);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = threadIdx.x + i * 256;
+    if (c < nch) {
+      const u32x4 wv = *(const u32x4*)(w + c * 8);
+      u32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float a = rbf(lo_bf(v[i][j]) * r) * lo_bf(wv[j]);
+        const float b = rbf(hi_bf(v[i][j]) * r) * hi_bf(wv[j]);
+        o[j] = pack2(a, b);
+      }
+      *(u32x4*)(yr + c * 8) = o;
+    }
+  }
+}
+
+// y = bf16( (x - mean) * rstd * w + b ), biased variance, stats fp32 (torch.nn.LayerNorm on bf16)
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ w,
+                                                        const bf16_t* __restrict__ b, bf16_t* __restrict__ y, int ldy,
+                                                        int d, float eps) {
+  __shared__ float sh[4];
+  const int row = blockIdx.x;
+  const bf16_t* xr = x + (size_t)row * ldx;
+  bf16_t* yr = y + (size_t)row * ldy;
+  const int nch = d >> 3;
+  float f[4][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = threadIdx.x + i * 256;
+    if (c < nch) {
+      const u32x4 v = *(const u32x4*)(xr + c * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f[i][2 * j] = lo_bf(v[j]);
+        f[i][2 * j + 1] = hi_bf(v[j]);
+        s += f[i][2 * j] + f[i][2 * j + 1];
+      }
+    }
+  }
+  const float mean = block_sum(s, sh) / (float)d;
+  float vs = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = threadIdx.x + i * 256;
+    if (c < nch) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float t = f[i][j] - mean;
+        vs += t * t;
+      }
+    }
+  }
+  const float rstd = rsqrtf(block_sum(vs, sh) / (float)d + eps);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = threadIdx.x + i * 256;
+    if (c < nch) {
+      const u32x4 wv = *(const u32x4*)(w + c * 8);
+      const u32x4 bv = *(const u32x4*)(b + c * 8);
+      u32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float a0 = (f[i][2 * j] - mean) * rstd * lo_bf(wv[j]) + lo_bf(bv[j]);
+        const float a1 = (f[i][2 * j + 1] - mean) * rstd * hi_bf(wv[j]) + hi_bf(bv[j]);
+        o[j] = pack2(a0, a1);
+      }
+      *(u32x4*)(yr + c * 8) = o;
+    }
+  }
+}
+
+}  // namespace
+
+hipError_t launch_rmsnorm(const bf16_t* x, int ldx, const bf16_t* w, bf16_t* y, int ldy, int rows, int d, float eps,
+                          hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  if ((d & 7) || d > 8192) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(rmsnorm_kernel, dim3(rows), dim3(256), 0, s, x, ldx, w, y, ldy, d, eps);
+  return hipGetLastError();
+}
+
+hipError_t launch_layernorm(const bf16_t* x, int ldx, const bf16_t* w, const bf16_t* b, bf16_t* y, int ldy, int rows,
+                            int d, float eps, hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  if ((d & 7) || d > 8192) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(layernorm_kernel, dim3(rows), dim3(256), 0, s, x, ldx, w, b, y, ldy, d, eps);
+  return hipGetLastError();
+}

@@ -1,0 +1,141 @@
+"""GPU parity of the individual HIP kernels (called through the C ABI test hooks) against the torch-CPU
+ops the oracle is made of. Tolerance: max rel err <= 1e-2 (bf16), stated by BASELINE.json's north_star;
+most outputs are bit-identical, the rest differ by one bf16 ulp from fp32 summation order."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-2
+
+
+def _dev():
+    return torch.device('cuda')
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize('use_gemv,M', [(False, 300), (False, 128), (False, 1), (True, 1), (True, 8), (True, 16)])
+@pytest.mark.parametrize('epi', ['none', 'quickgelu', 'gelu', 'residual', 'swiglu', 'f32'])
+def test_gemm_epilogues(use_gemv, M, epi):
+    from oracle_amd import engine as E
+    if use_gemv and epi == 'quickgelu':
+        pytest.skip('decode path has no QuickGELU GEMM')
+    K, N = 512, 384
+    x = _rand((M, K), 1)
+    w = _rand((N, K), 2, 0.05)
+    bias = _rand((N,), 3, 0.1) if epi not in ('swiglu', 'f32') else None
+    res = _rand((M, N), 4) if epi == 'residual' else None
+    y = F.linear(x, w, bias)
+    if epi == 'quickgelu':
+        ref = y * torch.sigmoid(1.702 * y)
+    elif epi == 'gelu':
+        ref = F.gelu(y)
+    elif epi == 'residual':
+        ref = res + y
+    elif epi == 'swiglu':
+        ref = F.silu(y[:, :N // 2]) * y[:, N // 2:]
+    elif epi == 'f32':
+        ref = y.float()
+    else:
+        ref = y
+    d = _dev()
+    out = E.test_gemm(x.to(d), w.to(d), None if bias is None else bias.to(d), None if res is None else res.to(d), epi, use_gemv)
+    torch.cuda.synchronize()
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) <= TOL
+    exact = (out.float().cpu() == ref.float()).float().mean().item()
+    assert exact > 0.6, f'only {exact:.3f} of the outputs are bit-identical'
+
+
+@pytest.mark.parametrize('K,N', [(4096, 4096), (11008, 4096), (4096, 256), (640, 1024)])
+def test_gemm_shapes(K, N):
+    from oracle_amd import engine as E
+    M = 257
+    x = _rand((M, K), 5)
+    w = _rand((N, K), 6, 0.02)
+    ref = F.linear(x, w)
+    d = _dev()
+    out = E.test_gemm(x.to(d), w.to(d))
+    assert rel_err(out, ref) <= TOL
+    out2 = E.test_gemm(x[:8].contiguous().to(d), w.to(d), use_gemv=True)
+    assert rel_err(out2, ref[:8]) <= TOL
+
+
+def test_norms():
+    from oracle_amd import engine as E
+    d = _dev()
+    for dim in (512, 1024, 4096):
+        x = _rand((37, dim), 7, 3.0)
+        w = (1 + 0.1 * _rand((dim,), 8).float()).to(torch.bfloat16)
+        b = _rand((dim,), 9, 0.1)
+        xf = x.float()
+        ref = w * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5)).to(torch.bfloat16)
+        out = E.test_rmsnorm(x.to(d), w.to(d), 1e-5)
+        assert rel_err(out, ref) <= TOL
+        assert (out.cpu() == ref).float().mean() > 0.98
+        ref = F.layer_norm(x, (dim,), w, b, 1e-5)
+        out = E.test_layernorm(x.to(d), w.to(d), b.to(d), 1e-5)
+        assert rel_err(out, ref) <= TOL
+        assert (out.cpu() == ref).float().mean() > 0.98
+
+
+def _eager(q, k, v, add, scale):
+    w = torch.matmul(q, k.transpose(-1, -2)) * scale
+    if add is not None:
+        w = w + add
+    w = F.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)
+    return torch.matmul(w, v)
+
+
+@pytest.mark.parametrize('hd,H,Sq', [(64, 3, 577), (128, 2, 200), (128, 2, 64), (64, 2, 33)])
+def test_attention_plain(hd, H, Sq):
+    from oracle_amd import engine as E
+    B = 2
+    q, k, v = _rand((B, H, Sq, hd), 10), _rand((B, H, Sq, hd), 11), _rand((B, H, Sq, hd), 12)
+    ref = _eager(q, k, v, None, hd ** -0.5)
+    d = _dev()
+    out = E.test_attention(q.to(d), k.to(d), v.to(d))
+    assert rel_err(out, ref) <= TOL
+
+
+def test_attention_causal_leftpad():
+    from oracle_amd import engine as E
+    B, H, S, hd = 3, 2, 150, 128
+    q, k, v = _rand((B, H, S, hd), 13), _rand((B, H, S, hd), 14), _rand((B, H, S, hd), 15)
+    pad = [0, 37, 100]
+    dt = torch.bfloat16
+    i = torch.arange(S)[:, None]
+    j = torch.arange(S)[None, :]
+    add = torch.zeros(B, 1, S, S, dtype=dt)
+    for b in range(B):
+        ok = (j <= i) & (j >= pad[b])
+        add[b, 0].masked_fill_(~ok, torch.finfo(dt).min)
+    ref = _eager(q, k, v, add, hd ** -0.5)
+    d = _dev()
+    kbeg = torch.tensor(pad, dtype=torch.int32, device=d)
+    out = E.test_attention(q.to(d), k.to(d), v.to(d), kbeg=kbeg, causal=True).cpu()
+    for b in range(B):   # rows inside the padding are never read by the path
+        assert rel_err(out[b, :, pad[b]:], ref[b, :, pad[b]:]) <= TOL
+        assert torch.isfinite(out[b].float()).all()
+
+
+def test_attention_key_padding():
+    from oracle_amd import engine as E
+    B, H, S, hd = 2, 2, 1152, 128
+    q, k, v = _rand((B, H, S, hd), 16), _rand((B, H, S, hd), 17), _rand((B, H, S, hd), 18)
+    valid = [1152, 576]
+    dt = torch.bfloat16
+    add = torch.zeros(B, 1, 1, S, dtype=dt)
+    for b in range(B):
+        add[b, 0, 0, valid[b]:] = torch.finfo(dt).min
+    ref = _eager(q, k, v, add, hd ** -0.5)
+    d = _dev()
+    kend = torch.tensor(valid, dtype=torch.int32, device=d)
+    out = E.test_attention(q.to(d), k.to(d), v.to(d), kend=kend)
+    assert rel_err(out, ref) <= TOL
