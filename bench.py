@@ -1,0 +1,222 @@
+#!/usr/bin/env python
+"""Headline benchmark: scene graphs (frames)/sec, 3-view ORacle LLaVA-7B bf16 (BASELINE.json configs[2]).
+
+One "step" = one batch of B=8 synthetic frames through the whole hot path behind the reference's own entry point
+LlavaLlamaForCausalLM.generate(): CLIP ViT-L/14-336 on 3 views per frame -> learned multi-view pooler -> mlp2x_gelu
+projector -> splice into the Vicuna-v1 ORacle prompt -> LLaMA-7B prefill (32 layers) -> KV-cached greedy decode of
+--new-tokens tokens (default 150 = mean 4D-OR answer length; random-init weights never emit EOS, so
+the stop is by length) -> token ids on the host. Inputs (bf16 image tensors, prompt ids) are resident in HBM before
+the timed region. Multi-GPU: frames are sharded (one engine replica per rank, weak scaling); the only collective is
+an RCCL all-gather of the generated token ids per step.
+
+Prints ONE JSON line (rank 0). Extra objects: "roofline" for the dominant kernel (gate/up projection GEMV of decode,
+HBM-bound; duration from HIP events recorded on the launch stream inside the timed region) and "cpu_baseline"
+(the CPU oracle timed on this host's cores on a bounded, stated sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def build_inputs(tokenizer, batch, views, dims, device, prompt_kind='plain'):
+    import torch
+    from oracle_amd.llava.conversation import default_conversation
+    from oracle_amd.llava.mm_utils import tokenizer_image_token
+    from oracle_amd.scene_graph_prediction import prompts
+    from oracle_amd.synth import synth_images
+    inp = {'plain': prompts.plain_prompt, 'symbolic': prompts.symbolic_prompt}[prompt_kind]()
+    conv = default_conversation.copy()
+    conv.append_message(conv.roles[0], '<image>\n' + inp)
+    conv.append_message(conv.roles[1], None)
+    ids = tokenizer_image_token(conv.get_prompt(), tokenizer, return_tensors='pt')
+    input_ids = ids[None].repeat(batch, 1).to(device)
+    images = synth_images(batch, views, dims).to(device)
+    return input_ids, images
+
+
+def cpu_baseline(new_tokens, views, prompt_len_spliced):
+    """The CPU oracle (oracle/cpu_ref.py, fp32, all host threads) on a bounded sample of one frame of the same
+    workload: CLIP on ONE view through 2 of the 23 layers, ONE LLaMA layer of prefill at the full spliced prompt
+    length, ONE LLaMA layer of one decode step + the lm_head; scaled by the layer / view / token counts."""
+    import torch
+    from oracle import cpu_ref as cr
+    from oracle_amd.dims import Dims
+    from oracle_amd.synth import synth_images, synth_state
+    d = Dims(n_layers=1, clip_layers=3)
+    torch.manual_seed(0)
+    st = synth_state(d, seed=0, dtype=torch.float32)
+    cores = torch.get_num_threads()
+    with torch.inference_mode():
+        img = synth_images(1, 1, d).float()
+        cr.vision_tower(st, d, img[:1])                              # warm
+        t0 = time.perf_counter(); cr.vision_tower(st, d, img[:1]); t_clip2 = time.perf_counter() - t0
+        feats = torch.randn(1, views * 576, 1024)
+        mask = torch.ones(1, views * 576, dtype=torch.bool)
+        t0 = time.perf_counter(); pooled = cr.image_pooler(st, d, feats, mask); proj = cr.mm_projector(st, pooled)
+        t_pool = time.perf_counter() - t0
+        T = prompt_len_spliced
+        emb = torch.randn(1, T, d.d_model) * 0.02
+        m = torch.ones(1, T, dtype=torch.bool)
+        pos = torch.arange(T)[None]
+        t0 = time.perf_counter(); _, kv = cr.llama_forward(st, d, emb, m, pos); t_pre1 = time.perf_counter() - t0
+        e1 = torch.randn(1, 1, d.d_model) * 0.02
+        m1 = torch.ones(1, T + 1, dtype=torch.bool)
+        p1 = torch.tensor([[T]])
+        cr.llama_forward(st, d, e1, m1, p1, kv)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            cr.llama_forward(st, d, e1, m1, p1, kv)
+        t_dec1 = (time.perf_counter() - t0) / 3                       # 1 layer + final norm + lm_head
+        h = torch.randn(1, 1, d.d_model)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            torch.nn.functional.linear(h, st['lm_head.weight'])
+        t_head = (time.perf_counter() - t0) / 3
+    L = 32
+    per_frame = (t_clip2 / 2 * 23 * views + t_pool + (t_pre1 - t_head) * L + t_head
+                 + new_tokens * ((t_dec1 - t_head) * L + t_head))
+    return {'value': 1.0 / per_frame, 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+            'sample': (f'fp32 CPU oracle, 1 frame: CLIP 1 view x 2 layers ({t_clip2:.2f}s) scaled to {views} views x 23 layers; '
+                       f'pooler+projector ({t_pool:.2f}s); 1 LLaMA layer prefill T={prompt_len_spliced} ({t_pre1:.2f}s) x32; '
+                       f'1 layer decode step ({t_dec1 * 1e3:.0f}ms incl. lm_head {t_head * 1e3:.0f}ms) x32 x {new_tokens} tokens'),
+            's_per_frame': per_frame}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--batch', type=int, default=8)
+    ap.add_argument('--views', type=int, default=3)
+    ap.add_argument('--new-tokens', type=int, default=150)
+    ap.add_argument('--prompt', default='plain', choices=['plain', 'symbolic'])
+    ap.add_argument('--dims', default='full', choices=['full', 'tiny'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from oracle_amd import synth
+    from oracle_amd.dims import FULL, TINY
+    from oracle_amd.engine import Engine
+    from oracle_amd.llava.model.language_model.llava_llama import LlavaConfig, LlavaLlamaForCausalLM
+    from oracle_amd.tokenizer import SynthTokenizer
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+    dims = FULL if a.dims == 'full' else TINY
+
+    torch.manual_seed(1234 + rank)
+    state = synth.synth_state(dims, seed=0, device=dev, device_fast=(dims is FULL))
+    tok = SynthTokenizer(dims.vocab)
+    probe_ids, _ = build_inputs(tok, 1, 1, dims, 'cpu', a.prompt)
+    T = probe_ids.shape[1] - 1 + 576
+    eng = Engine(dims, max_batch=a.batch, max_seq=T + a.new_tokens + 8, max_images=a.batch * a.views,
+                 max_new_tokens=max(a.new_tokens, 16), pad_token_id=0, eos_token_id=-1, device=dev)
+    eng.load_state(state)
+    del state
+    torch.cuda.empty_cache()
+    cfg = LlavaConfig(dims, tokenizer_padding_side='left', mv_type='learned' if a.views > 1 else 'concat', eos_token_id=-1)
+    model = LlavaLlamaForCausalLM(cfg, eng)
+    input_ids, images = build_inputs(tok, a.batch, a.views, dims, dev, a.prompt)
+    gathered = torch.empty(world * a.batch, a.new_tokens, dtype=torch.int32, device=dev) if world > 1 else None
+
+    def step():
+        out = model.generate(input_ids, images=images, do_sample=False, use_cache=True, max_new_tokens=a.new_tokens,
+                             chunk=a.new_tokens)
+        new = out[:, input_ids.shape[1]:]
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, new.to(torch.int32).contiguous())
+        return new
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    eng.profile_enable(True)
+    sync()
+    lat = []
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        s0 = time.perf_counter()
+        new = step()
+        lat.append(time.perf_counter() - s0)
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof_ms, prof_n, prof_bytes = eng.profile_read()
+    eng.profile_enable(False)
+    assert new.shape[1] == a.new_tokens, new.shape
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # stage split of one step (untimed, diagnostic): vision+splice+prefill vs decode
+    sync()
+    s0 = time.perf_counter()
+    inp = model.prepare_inputs_for_generation(input_ids, attention_mask=torch.ones_like(input_ids, dtype=torch.bool), images=images)
+    _, pos, mask, _, emb, _ = model.prepare_inputs_labels_for_multimodal(inp['input_ids'], inp['position_ids'], inp['attention_mask'],
+                                                                         None, None, images, None)
+    torch.cuda.synchronize()
+    t_vis = time.perf_counter() - s0
+    s0 = time.perf_counter()
+    eng.prefill(emb.contiguous(), pos.to(torch.int32).contiguous(), [0] * a.batch)
+    torch.cuda.synchronize()
+    t_pre = time.perf_counter() - s0
+    s0 = time.perf_counter()
+    eng.decode_steps(a.new_tokens - 1)
+    torch.cuda.synchronize()
+    t_dec = time.perf_counter() - s0
+
+    if rank == 0:
+        frames = world * a.steps * a.batch
+        lat.sort()
+        avg_us = prof_ms * 1e3 / max(prof_n, 1)
+        achieved = prof_bytes / (avg_us * 1e-6) / 1e9 if prof_n else 0.0
+        dec_ms = t_dec * 1e3 / max(a.new_tokens - 1, 1)
+        ctx = T + a.new_tokens / 2
+        dec_bytes = eng.decode_weight_bytes() + eng.kv_bytes_per_key() * ctx * a.batch
+        res = {
+            'metric': 'scene graphs (frames)/sec whole node, 3-view LLaVA-7B bf16; p50 frame latency',
+            'value': frames / elapsed, 'unit': 'frames/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': elapsed / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': f'BASELINE configs[2]: {a.views}-view ORacle LLaVA-7B (mv_type={cfg.mv_type}), batch {a.batch} frames/step/GPU, '
+                                   f'{a.prompt} ORacle prompt (spliced T={T}), greedy decode {a.new_tokens} new tokens/frame (length stop; '
+                                   f'random-init weights), full generate() incl. CLIP x{a.views * a.batch}, pooler, projector, splice, 32-layer prefill',
+                       'dims': a.dims, 'batch': a.batch, 'views': a.views, 'new_tokens': a.new_tokens, 'prompt_tokens_spliced': T,
+                       'parallelism': f'dp{world} (frame sharding, RCCL all-gather of token ids)'},
+            'p50_frame_latency_ms': lat[len(lat) // 2] * 1e3,
+            'stage_ms': {'vision_fuse_splice': t_vis * 1e3, 'prefill': t_pre * 1e3, 'decode_total': t_dec * 1e3, 'decode_per_token': dec_ms},
+            'decode_step': {'algorithmic_bytes': dec_bytes, 'achieved_GBps': dec_bytes / (dec_ms * 1e-3) / 1e9,
+                            'frac_of_hbm_peak': dec_bytes / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            'roofline': {'kernel': 'gemv_kernel<2,SWIGLU> (decode gate/up projection, 22016x4096 bf16 weights)', 'bound': 'hbm',
+                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': None, 'launches_timed': prof_n, 'avg_launch_us': avg_us, 'algorithmic_bytes_per_launch': prof_bytes},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(a.new_tokens, a.views, T)
+        print(json.dumps(res), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

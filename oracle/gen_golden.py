@@ -29,7 +29,8 @@ def sub2(x, s0, s1):
     """Strided subset over the last two dims + checksums of the full tensor."""
     x = x.detach().float()
     return {'sub': x[..., ::s0, ::s1].numpy(), 'sum': np.float64(x.double().sum().item()),
-            'abssum': np.float64(x.double().abs().sum().item()), 'shape': np.array(x.shape)}
+            'abssum': np.float64(x.double().abs().sum().item()), 'absmax': np.float64(x.abs().max().item()),
+            'shape': np.array(x.shape)}
 
 
 def save(name, **arrs):
@@ -238,6 +239,15 @@ def gen_text():
     kat['vicuna_v1_prompt'] = conv.get_prompt()
     kat['default_conversation_is_vicuna_v1'] = ns.conversation.default_conversation.name if hasattr(ns.conversation.default_conversation, 'name') else None
     kat['sep2'] = conv.sep2
+    # the user-turn prompt literals of OracleWrapper.forward (…_oracle.py:72-81): only their digests are stored
+    import hashlib
+    import re
+    src = open(os.path.join(rh.REF_ROOT, 'scene_graph_prediction/scene_graph_helpers/model/scene_graph_prediction_model_oracle.py')).read()
+    lits = re.findall(r"inp = f?'(Entities.*?)'\n", src)
+    names = ['symbolic', 'plain', 'visual', 'visual_mv']
+    kat['prompt_digest'] = {n: {'sha256': hashlib.sha256(l.replace('{VIS_DESCRIPTOR_TOKEN}', ns.constants.VIS_DESCRIPTOR_TOKEN).encode()).hexdigest(),
+                                'chars': len(l.replace('{VIS_DESCRIPTOR_TOKEN}', ns.constants.VIS_DESCRIPTOR_TOKEN))}
+                            for n, l in zip(names, lits)}
     path = os.path.join(OUT, 'text_kat.json')
     with open(path, 'w') as f:
         json.dump(kat, f, indent=1, ensure_ascii=False)

@@ -46,6 +46,8 @@ SYMBOLS = {
     'orc_test_rmsnorm': (_I, [_P, _P, _I, _I, _F, _P, _P]),
     'orc_test_layernorm': (_I, [_P, _P, _P, _I, _I, _F, _P, _P]),
     'orc_test_attention': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _F, _P, _P]),
+    'orc_profile_enable': (_I, [_P, _I]),
+    'orc_profile_read': (_I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(_L)]),
     'orc_decode_weight_bytes': (_L, [_P]),
     'orc_kv_bytes_per_key': (_L, [_P]),
 }
@@ -62,6 +64,9 @@ def lib():
             raise OracleHipError(
                 f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                 '(hipcc --offload-arch=gfx950). There is no fallback path.')
+        # torch ships its own HIP runtime: load it first so this library binds to the same libamdhip64 the
+        # process uses for device memory and streams (a second runtime would not see torch's allocations)
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)

@@ -98,6 +98,10 @@ struct orc_engine {
   int *d_step, *d_curlen, *d_nunf, *d_unf, *d_next, *d_argmax, *d_kbeg, *d_kend, *d_rowoff, *d_rowvalid, *d_tokens;
   int* h_pinned = nullptr;   // pinned host staging (small int arrays)
   int cur_batch = 0, cur_T = 0;
+  // sampled HIP-event timing of the dominant decode kernel (gate/up GEMV), see orc_profile_*
+  bool prof_on = false;
+  std::vector<hipEvent_t> ev_a, ev_b;
+  int ev_used = 0;
 
   int alloc(void** p, size_t bytes) {
     hipError_t e = hipMalloc(p, bytes ? bytes : 16);
@@ -613,7 +617,10 @@ static int llama_layers(orc_engine* e, bf16_t* h, bf16_t* xn, bf16_t* qkv, bf16_
     }
     ORCCHK(gemm(att, d, L.o, nullptr, h, d, h, d, M, EPI_RESIDUAL, s, decode));
     HIPCHK(launch_rmsnorm(h, d, L.ln_post, xn, d, M, d, c.rms_eps, s));
+    const bool sample = decode && e->prof_on && (i % 8 == 0) && e->ev_used < (int)e->ev_a.size();
+    if (sample) HIPCHK(hipEventRecord(e->ev_a[e->ev_used], s));
     ORCCHK(gemm(xn, d, L.gu, nullptr, nullptr, 0, mlp, c.d_ff, M, EPI_SWIGLU, s, decode));
+    if (sample) HIPCHK(hipEventRecord(e->ev_b[e->ev_used++], s));
     ORCCHK(gemm(mlp, c.d_ff, L.down, nullptr, h, d, h, d, M, EPI_RESIDUAL, s, decode));
   }
   return 0;
@@ -698,6 +705,37 @@ extern "C" int orc_read_state(orc_engine* e, int32_t* tokens_host, int32_t* step
   HIPCHK(hipStreamSynchronize(s));
   if (steps_host) *steps_host = hdr[0];
   if (n_unf_host) *n_unf_host = hdr[2];
+  return 0;
+}
+
+extern "C" int orc_profile_enable(orc_engine* e, int on) {
+  if (!e) return fail("orc_profile_enable", "null engine");
+  if (on && e->ev_a.empty()) {
+    e->ev_a.resize(4096);
+    e->ev_b.resize(4096);
+    for (size_t i = 0; i < e->ev_a.size(); ++i) {
+      HIPCHK(hipEventCreate(&e->ev_a[i]));
+      HIPCHK(hipEventCreate(&e->ev_b[i]));
+    }
+  }
+  e->prof_on = on != 0;
+  e->ev_used = 0;
+  return 0;
+}
+
+extern "C" int orc_profile_read(orc_engine* e, double* total_ms, int32_t* count, int64_t* bytes_per_launch) {
+  if (!e) return fail("orc_profile_read", "null engine");
+  HIPCHK(hipDeviceSynchronize());
+  double tot = 0.0;
+  for (int i = 0; i < e->ev_used; ++i) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e->ev_a[i], e->ev_b[i]));
+    tot += ms;
+  }
+  if (total_ms) *total_ms = tot;
+  if (count) *count = e->ev_used;
+  // algorithmic bytes of one gate/up GEMV launch: the two weight matrices (activations are L2-resident and small)
+  if (bytes_per_launch) *bytes_per_launch = (int64_t)2 * 2 * e->c.d_ff * e->c.d_model;
   return 0;
 }
 

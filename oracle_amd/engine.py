@@ -172,6 +172,15 @@ class Engine:
         t = torch.tensor(list(toks), dtype=torch.long).view(b, self.max_new_tokens)[:, :min(steps.value, self.max_new_tokens)]
         return t, steps.value, nunf.value, torch.tensor(list(am), dtype=torch.long)
 
+    def profile_enable(self, on=True):
+        _lib.check(self.lib.orc_profile_enable(self._h, 1 if on else 0), 'orc_profile_enable')
+
+    def profile_read(self):
+        """-> (total_ms, launches, algorithmic bytes per launch) of the sampled gate/up GEMV launches."""
+        ms, n, by = C.c_double(), C.c_int32(), C.c_int64()
+        _lib.check(self.lib.orc_profile_read(self._h, C.byref(ms), C.byref(n), C.byref(by)), 'orc_profile_read')
+        return ms.value, n.value, by.value
+
     def decode_weight_bytes(self):
         return int(self.lib.orc_decode_weight_bytes(self._h))
 
