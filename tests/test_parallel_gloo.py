@@ -1,0 +1,73 @@
+"""CPU, world_size 2 over gloo: frame sharding (round-robin; whole takes for the temporal variant) and the fixed-shape
+all-gather of token ids that is the only exchange of the multi-GPU path."""
+import os
+import socket
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from oracle_amd import parallel
+    r, w = parallel.init_from_env(backend='gloo')
+    n = 11
+    mine = parallel.shard_indices(n, r, w)
+    F = 6
+    toks = torch.full((F, 5), -1, dtype=torch.int32)
+    lens = torch.zeros(F, dtype=torch.int32)
+    for j, idx in enumerate(mine):
+        toks[j] = idx * 10 + torch.arange(5, dtype=torch.int32)
+        lens[j] = 1 + idx % 5
+    allbuf = parallel.gather_token_ids(toks, lens, w)
+    merged = parallel.gather_objects({f's{idx}': [idx] for idx in mine}, r, w)
+    groups = [4] * 5 + [8] * 6
+    tmine = parallel.shard_indices(n, r, w, groups=groups)
+    if r == 0:
+        torch.save({'allbuf': allbuf, 'merged': merged, 'mine': mine, 'tmine': tmine}, out)
+    dist.barrier()
+    parallel.finalize()
+
+
+def test_world2_sharding_and_gather(tmp_path):
+    out = str(tmp_path / 'r0.pt')
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    res = torch.load(out)
+    buf = res['allbuf']
+    assert buf.shape == (12, 6)
+    seen = {}
+    for row in buf.tolist():
+        if row[0] > 0:
+            idx = row[1] // 10
+            assert row[1:] == [idx * 10 + k for k in range(5)] and row[0] == 1 + idx % 5
+            seen[idx] = True
+    assert sorted(seen) == list(range(11))
+    assert sorted(res['merged']) == sorted(f's{i}' for i in range(11))
+    assert res['mine'] == [0, 2, 4, 6, 8, 10]
+    assert res['tmine'] == [5, 6, 7, 8, 9, 10]       # the larger take goes to rank 0, whole and in order
+
+
+def test_shard_properties():
+    from oracle_amd.parallel import shard_indices
+    for n in (0, 1, 7, 1378):
+        for w in (1, 2, 4, 8):
+            parts = [shard_indices(n, r, w) for r in range(w)]
+            assert sorted(sum(parts, [])) == list(range(n))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    groups = [2] * 700 + [6] * 678
+    parts = [shard_indices(1378, r, 8, groups=groups) for r in range(8)]
+    assert sorted(sum(parts, [])) == list(range(1378))
+    assert sum(1 for p in parts if p) == 2               # parallelism is bounded by the number of takes
