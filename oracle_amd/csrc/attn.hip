@@ -142,18 +142,21 @@ __device__ __forceinline__ float rescale(float m_old, float m_new) {
   return (m_old == -INFINITY) ? 0.f : __expf(m_old - m_new);
 }
 
-// grid (H, B, DECODE_NSPLIT), 256 threads. Lane layout: 16 lanes per key (8 head-dim elements each),
-// 4 keys per wave-instruction = one contiguous 1 KiB read of the cache.
-__global__ __launch_bounds__(256) void decode_attn_kernel(DecodeAttnArgs a) {
-  __shared__ float sh_m[4], sh_l[4];
-  __shared__ __attribute__((aligned(16))) float sh_acc[4][128];
+// grid (H, B, nsplit), WAVES*64 threads. Lane layout: 16 lanes per key (8 head-dim elements each),
+// 4 keys per wave-instruction = one contiguous 1 KiB read of the cache. With nsplit == 1 (enough (row, head) pairs to
+// fill the chip) the workgroup owns the whole key range and writes the bf16 output itself; otherwise partial
+// (m, l, acc) go to the workspace and decode_attn_combine_kernel merges them.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void decode_attn_kernel(DecodeAttnArgs a) {
+  __shared__ float sh_m[WAVES], sh_l[WAVES];
+  __shared__ __attribute__((aligned(16))) float sh_acc[WAVES][128];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int kq = lane >> 4, c = lane & 15;
-  const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
+  const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z, nsplit = gridDim.z;
   const int len = *a.cur_len;
   const int kb = a.kbeg[b];
   const int n = len - kb;
-  const int per = (n + DECODE_NSPLIT - 1) / DECODE_NSPLIT;
+  const int per = (n + nsplit - 1) / nsplit;
   const int k_lo = kb + sp * per;
   const int k_hi = (k_lo + per < len) ? k_lo + per : len;
 
@@ -171,12 +174,12 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecodeAttnArgs a) {
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 
   constexpr int U = 4;
-  for (int base = k_lo + w * 4; base < k_hi; base += 16 * U) {
+  for (int base = k_lo + w * 4; base < k_hi; base += 4 * WAVES * U) {
     u32x4 kv[U], vv[U];
     bool ok[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int key = base + u * 16 + kq;
+      const int key = base + u * 4 * WAVES + kq;
       ok[u] = key < k_hi;
       const int kc_ = ok[u] ? key : (k_hi - 1 > 0 ? k_hi - 1 : 0);
       kv[u] = __builtin_nontemporal_load((const u32x4*)(kc + (size_t)kc_ * 128));
@@ -226,18 +229,24 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecodeAttnArgs a) {
   }
   __syncthreads();
   if (tid < 128) {
-    float mm = fmaxf(fmaxf(sh_m[0], sh_m[1]), fmaxf(sh_m[2], sh_m[3]));
+    float mm = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < WAVES; ++i) mm = fmaxf(mm, sh_m[i]);
     const float m_use = (mm == -INFINITY) ? 0.f : mm;
     float ll = 0.f, av = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < WAVES; ++i) {
       const float sc = rescale(sh_m[i], m_use);
       ll += sh_l[i] * sc;
       av += sh_acc[i][tid] * sc;
     }
-    float* pp = a.part + (((size_t)b * a.H + h) * DECODE_NSPLIT + sp) * 130;
-    if (tid == 0) { pp[0] = mm; pp[1] = ll; }
-    pp[2 + tid] = av;
+    if (nsplit == 1) {
+      a.O[(size_t)b * a.o_bs + h * 128 + tid] = f2bf(ll > 0.f ? av / ll : 0.f);
+    } else {
+      float* pp = a.part + (((size_t)b * a.H + h) * DECODE_NSPLIT + sp) * 130;
+      if (tid == 0) { pp[0] = mm; pp[1] = ll; }
+      pp[2 + tid] = av;
+    }
   }
 }
 
@@ -274,7 +283,11 @@ hipError_t launch_attention(const AttnArgs& a, int head_dim, hipStream_t s) {
 
 hipError_t launch_decode_attention(const DecodeAttnArgs& a, hipStream_t s) {
   if (a.B <= 0) return hipSuccess;
-  hipLaunchKernelGGL(decode_attn_kernel, dim3(a.H, a.B, DECODE_NSPLIT), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(decode_attn_combine_kernel, dim3(a.H, a.B), dim3(128), 0, s, a);
+  if (a.B * a.H >= 192) {   // one workgroup of 16 waves per (row, head): fills the chip without a KV split
+    hipLaunchKernelGGL(decode_attn_kernel<16>, dim3(a.H, a.B, 1), dim3(1024), 0, s, a);
+  } else {
+    hipLaunchKernelGGL(decode_attn_kernel<4>, dim3(a.H, a.B, DECODE_NSPLIT), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(decode_attn_combine_kernel, dim3(a.H, a.B), dim3(128), 0, s, a);
+  }
   return hipGetLastError();
 }

@@ -52,7 +52,7 @@ struct PoolLayer {
 };
 struct LlamaLayer {
   bf16_t *ln_in, *ln_post;
-  Packed qkv, o, gu, down;
+  Packed qkv, qkv_dec, o, gu, down;
 };
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -93,6 +93,7 @@ struct orc_engine {
   bf16_t *w_h = nullptr, *w_xn = nullptr, *w_qkv = nullptr, *w_att = nullptr, *w_mlp = nullptr, *w_aux = nullptr;
   float* w_logits = nullptr;
   float* w_part = nullptr;
+  float* d_ssq = nullptr;   // [16][d_model/16] per-n-tile sums of squares of the decode hidden state
   bf16_t *d_h = nullptr, *d_xn = nullptr, *d_qkv = nullptr, *d_att = nullptr, *d_mlp = nullptr;   // decode (<=16 rows)
   int *dev_ints = nullptr;   // [0]=step [1]=cur_len [2]=n_unfinished, then per-row arrays
   int *d_step, *d_curlen, *d_nunf, *d_unf, *d_next, *d_argmax, *d_kbeg, *d_kend, *d_rowoff, *d_rowvalid, *d_tokens;
@@ -370,6 +371,13 @@ extern "C" int orc_engine_finalize(orc_engine* e) {
     const int t = pr / 32, wi = pr % 32;   // gate tile, up tile alternate every 16 rows
     gu_map[pr] = wi < 16 ? 16 * t + wi : c.d_ff + 16 * t + (wi - 16);
   }
+  // decode copy of the fused q/k/v weight: inside every 128-row head section tile j is followed by tile j+4, so one
+  // workgroup of the decode GEMV holds a head dim and its rotary partner (d, d+64) in the same lane
+  std::vector<int> qkv_dec_map(3 * c.d_model);
+  for (int pr = 0; pr < 3 * c.d_model; ++pr) {
+    const int p = pr / 16, rr = pr % 16, pair = p / 2, which = p % 2, hs = pair / 4, j = pair % 4;
+    qkv_dec_map[pr] = hs * 128 + (j + 4 * which) * 16 + rr;
+  }
   for (int i = 0; i < c.n_layers; ++i) {
     snprintf(buf, sizeof(buf), "model.layers.%d.", i);
     const std::string q = buf;
@@ -378,6 +386,7 @@ extern "C" int orc_engine_finalize(orc_engine* e) {
     ORCCHK(take(e, q + "post_attention_layernorm.weight", &L.ln_post, c.d_model));
     std::vector<std::string> w3 = {q + "self_attn.q_proj.weight", q + "self_attn.k_proj.weight", q + "self_attn.v_proj.weight"};
     ORCCHK(pack_rows(e, w3, c.d_model, nullptr, 128, &L.qkv));
+    ORCCHK(pack_rows(e, w3, c.d_model, &qkv_dec_map, 128, &L.qkv_dec));
     ORCCHK(pack_rows(e, {q + "self_attn.o_proj.weight"}, c.d_model, nullptr, 128, &L.o));
     std::vector<std::string> w2 = {q + "mlp.gate_proj.weight", q + "mlp.up_proj.weight"};
     ORCCHK(pack_rows(e, w2, c.d_model, &gu_map, 128, &L.gu));
@@ -436,6 +445,7 @@ extern "C" int orc_engine_finalize(orc_engine* e) {
     ORCCHK(e->alloc((void**)&e->w_mlp, (size_t)rows * wm * 2));
     ORCCHK(e->alloc((void**)&e->w_logits, (size_t)16 * c.vocab * 4));
     ORCCHK(e->alloc((void**)&e->w_part, (size_t)16 * c.n_heads * DECODE_NSPLIT * 130 * 4));
+    ORCCHK(e->alloc((void**)&e->d_ssq, (size_t)16 * (c.d_model / 16) * 4));
     ORCCHK(e->alloc((void**)&e->d_h, (size_t)16 * c.d_model * 2));
     ORCCHK(e->alloc((void**)&e->d_xn, (size_t)16 * c.d_model * 2));
     ORCCHK(e->alloc((void**)&e->d_att, (size_t)16 * c.d_model * 2));
@@ -584,8 +594,23 @@ extern "C" int orc_splice(orc_engine* e, const int32_t* codes, int rows, const v
 }
 
 // ============================================================================ LLaMA
-static int llama_layers(orc_engine* e, bf16_t* h, bf16_t* xn, bf16_t* qkv, bf16_t* att, bf16_t* mlp, int B, int T,
-                        const int32_t* pos, bool decode, hipStream_t s) {
+static int gemv_ex(orc_engine* e, const bf16_t* X, int ldx, const Packed& W, const bf16_t* R, void* C, int ldc, int M, int epi,
+                   hipStream_t s, bf16_t* kc = nullptr, bf16_t* vc = nullptr, float* ssq_out = nullptr) {
+  const orc_config& c = e->c;
+  GemvArgs a = {};
+  a.X = X; a.ldx = ldx; a.Wp = W.p; a.bias = nullptr; a.R = R; a.ldr = ldc; a.C = C; a.ldc = ldc;
+  a.M = M; a.N = W.N; a.K = W.K; a.Nvalid = (epi == EPI_SWIGLU) ? W.Nvalid / 2 : W.Nvalid;
+  a.H = c.n_heads; a.kbeg = e->d_kbeg; a.cur_len = e->d_curlen; a.cos_tab = e->cos_tab; a.sin_tab = e->sin_tab;
+  a.maxpos = e->maxpos; a.Kc = kc; a.Vc = vc; a.c_bs = e->c_bs; a.c_hs = e->c_hs;
+  a.ssq_out = ssq_out;
+  hipError_t err = launch_gemv_ex(a, epi, 0, s);
+  if (err != hipSuccess) return fail("launch_gemv_ex", hipGetErrorString(err));
+  return 0;
+}
+
+// prefill: tiled MFMA GEMMs + flash attention over all B*T positions
+static int llama_prefill_layers(orc_engine* e, bf16_t* h, bf16_t* xn, bf16_t* qkv, bf16_t* att, bf16_t* mlp, int B, int T,
+                                const int32_t* pos, hipStream_t s) {
   const orc_config& c = e->c;
   const int d = c.d_model, M = B * T;
   for (int i = 0; i < c.n_layers; ++i) {
@@ -593,43 +618,67 @@ static int llama_layers(orc_engine* e, bf16_t* h, bf16_t* xn, bf16_t* qkv, bf16_
     bf16_t* kc = e->kcache + (size_t)i * e->kv_layer_elems;
     bf16_t* vc = e->vcache + (size_t)i * e->kv_layer_elems;
     HIPCHK(launch_rmsnorm(h, d, L.ln_in, xn, d, M, d, c.rms_eps, s));
-    ORCCHK(gemm(xn, d, L.qkv, nullptr, nullptr, 0, qkv, 3 * d, M, EPI_NONE, s, decode));
+    ORCCHK(gemm(xn, d, L.qkv, nullptr, nullptr, 0, qkv, 3 * d, M, EPI_NONE, s, false));
     RopeArgs r;
-    r.qkv = qkv; r.B = B; r.T = T; r.H = c.n_heads; r.pos = decode ? nullptr : pos; r.kbeg = e->d_kbeg; r.cur_len = e->d_curlen;
+    r.qkv = qkv; r.B = B; r.T = T; r.H = c.n_heads; r.pos = pos; r.kbeg = e->d_kbeg; r.cur_len = e->d_curlen;
     r.cos_tab = e->cos_tab; r.sin_tab = e->sin_tab; r.maxpos = e->maxpos; r.Kc = kc; r.Vc = vc; r.c_bs = e->c_bs; r.c_hs = e->c_hs;
     r.t0 = 0;
     HIPCHK(launch_rope_kv(r, s));
-    if (!decode) {
-      AttnArgs a;
-      a.Q = qkv; a.q_bs = (long)T * 3 * d; a.q_hs = 128; a.q_ts = 3 * d;
-      a.K = kc; a.k_bs = e->c_bs; a.k_hs = e->c_hs; a.k_ts = 128;
-      a.V = vc; a.v_bs = e->c_bs; a.v_hs = e->c_hs; a.v_ts = 128;
-      a.O = att; a.o_bs = (long)T * d; a.o_hs = 128; a.o_ts = d;
-      a.B = B; a.H = c.n_heads; a.Sq = T; a.Sk = T; a.kbeg = e->d_kbeg; a.kend = nullptr; a.causal = 1; a.q_off = 0;
-      a.scale = 0.08838834764831845f;
-      HIPCHK(launch_attention(a, 128, s));
-    } else {
-      DecodeAttnArgs a;
-      a.Q = qkv; a.q_bs = 3 * d; a.Kc = kc; a.Vc = vc; a.c_bs = e->c_bs; a.c_hs = e->c_hs; a.O = att; a.o_bs = d;
-      a.part = e->w_part; a.kbeg = e->d_kbeg; a.cur_len = e->d_curlen; a.B = B; a.H = c.n_heads;
-      a.scale = 0.08838834764831845f;
-      HIPCHK(launch_decode_attention(a, s));
-    }
-    ORCCHK(gemm(att, d, L.o, nullptr, h, d, h, d, M, EPI_RESIDUAL, s, decode));
+    AttnArgs a;
+    a.Q = qkv; a.q_bs = (long)T * 3 * d; a.q_hs = 128; a.q_ts = 3 * d;
+    a.K = kc; a.k_bs = e->c_bs; a.k_hs = e->c_hs; a.k_ts = 128;
+    a.V = vc; a.v_bs = e->c_bs; a.v_hs = e->c_hs; a.v_ts = 128;
+    a.O = att; a.o_bs = (long)T * d; a.o_hs = 128; a.o_ts = d;
+    a.B = B; a.H = c.n_heads; a.Sq = T; a.Sk = T; a.kbeg = e->d_kbeg; a.kend = nullptr; a.causal = 1; a.q_off = 0;
+    a.scale = 0.08838834764831845f;
+    HIPCHK(launch_attention(a, 128, s));
+    ORCCHK(gemm(att, d, L.o, nullptr, h, d, h, d, M, EPI_RESIDUAL, s, false));
     HIPCHK(launch_rmsnorm(h, d, L.ln_post, xn, d, M, d, c.rms_eps, s));
-    const bool sample = decode && e->prof_on && (i % 8 == 0) && e->ev_used < (int)e->ev_a.size();
-    if (sample) HIPCHK(hipEventRecord(e->ev_a[e->ev_used], s));
-    ORCCHK(gemm(xn, d, L.gu, nullptr, nullptr, 0, mlp, c.d_ff, M, EPI_SWIGLU, s, decode));
-    if (sample) HIPCHK(hipEventRecord(e->ev_b[e->ev_used++], s));
-    ORCCHK(gemm(mlp, c.d_ff, L.down, nullptr, h, d, h, d, M, EPI_RESIDUAL, s, decode));
+    ORCCHK(gemm(xn, d, L.gu, nullptr, nullptr, 0, mlp, c.d_ff, M, EPI_SWIGLU, s, false));
+    ORCCHK(gemm(mlp, c.d_ff, L.down, nullptr, h, d, h, d, M, EPI_RESIDUAL, s, false));
   }
   return 0;
 }
 
-static int head_and_sample(orc_engine* e, const bf16_t* hrows, int ldh, int B, float* logits_out, hipStream_t s) {
+// decode: 7 launches per layer --
+//   [RMSNorm from partials] [qkv GEMV + rotary + KV write] [attention over the cache] [o_proj GEMV + residual + ssq partials]
+//   [RMSNorm from partials] [gate/up GEMV + SiLU*mul] [down GEMV + residual + ssq partials]
+// The residual epilogues leave per-n-tile sums of squares of the new hidden state in d_ssq, so the norms are
+// elementwise (no reduction pass, many small workgroups).
+static int llama_decode_layers(orc_engine* e, int B, hipStream_t s) {
   const orc_config& c = e->c;
-  HIPCHK(launch_rmsnorm(hrows, ldh, e->final_norm, e->d_xn, c.d_model, B, c.d_model, c.rms_eps, s));
-  ORCCHK(gemm(e->d_xn, c.d_model, e->lm_head, nullptr, nullptr, 0, e->w_logits, c.vocab, B, EPI_F32, s, true));
+  const int d = c.d_model, np = d / 16;
+  bf16_t *h = e->d_h, *xn = e->d_xn, *q = e->d_qkv, *att = e->d_att, *mlp = e->d_mlp;
+  for (int i = 0; i < c.n_layers; ++i) {
+    const LlamaLayer& L = e->llama[i];
+    bf16_t* kc = e->kcache + (size_t)i * e->kv_layer_elems;
+    bf16_t* vc = e->vcache + (size_t)i * e->kv_layer_elems;
+    HIPCHK(launch_rmsnorm_part(h, d, e->d_ssq, np, L.ln_in, xn, d, B, d, c.rms_eps, s));
+    ORCCHK(gemv_ex(e, xn, d, L.qkv_dec, nullptr, q, d, B, EPI_ROPE_KV, s, kc, vc));
+    DecodeAttnArgs a;
+    a.Q = q; a.q_bs = d; a.Kc = kc; a.Vc = vc; a.c_bs = e->c_bs; a.c_hs = e->c_hs; a.O = att; a.o_bs = d;
+    a.part = e->w_part; a.kbeg = e->d_kbeg; a.cur_len = e->d_curlen; a.B = B; a.H = c.n_heads;
+    a.scale = 0.08838834764831845f;
+    HIPCHK(launch_decode_attention(a, s));
+    ORCCHK(gemv_ex(e, att, d, L.o, h, h, d, B, EPI_RESIDUAL, s, nullptr, nullptr, e->d_ssq));
+    HIPCHK(launch_rmsnorm_part(h, d, e->d_ssq, np, L.ln_post, xn, d, B, d, c.rms_eps, s));
+    const bool sample = e->prof_on && (i % 8 == 0) && e->ev_used < (int)e->ev_a.size();
+    if (sample) HIPCHK(hipEventRecord(e->ev_a[e->ev_used], s));
+    ORCCHK(gemv_ex(e, xn, d, L.gu, nullptr, mlp, c.d_ff, B, EPI_SWIGLU, s));
+    if (sample) HIPCHK(hipEventRecord(e->ev_b[e->ev_used++], s));
+    ORCCHK(gemv_ex(e, mlp, c.d_ff, L.down, h, h, d, B, EPI_RESIDUAL, s, nullptr, nullptr, e->d_ssq));
+  }
+  return 0;
+}
+
+// final RMSNorm + lm_head + greedy sampling. from_decode: hrows = d_h with fresh partials in d_ssq.
+static int head_and_sample(orc_engine* e, const bf16_t* hrows, int ldh, int B, float* logits_out, bool from_decode, hipStream_t s) {
+  const orc_config& c = e->c;
+  if (from_decode)
+    HIPCHK(launch_rmsnorm_part(hrows, ldh, e->d_ssq, c.d_model / 16, e->final_norm, e->d_xn, c.d_model, B, c.d_model, c.rms_eps, s));
+  else
+    HIPCHK(launch_rmsnorm(hrows, ldh, e->final_norm, e->d_xn, c.d_model, B, c.d_model, c.rms_eps, s));
+  ORCCHK(gemv_ex(e, e->d_xn, c.d_model, e->lm_head, nullptr, e->w_logits, c.vocab, B, EPI_F32, s));
   if (logits_out)
     HIPCHK(hipMemcpyAsync(logits_out, e->w_logits, (size_t)B * c.vocab * 4, hipMemcpyDeviceToDevice, s));
   SampleArgs a;
@@ -666,18 +715,18 @@ extern "C" int orc_prefill(orc_engine* e, const void* embeds, const int32_t* pos
   e->cur_T = T;
   const int d = c.d_model, M = B * T;
   HIPCHK(hipMemcpyAsync(e->w_h, embeds, (size_t)M * d * 2, hipMemcpyDeviceToDevice, s));
-  ORCCHK(llama_layers(e, e->w_h, e->w_xn, e->w_qkv, e->w_att, e->w_mlp, B, T, position_ids, false, s));
+  ORCCHK(llama_prefill_layers(e, e->w_h, e->w_xn, e->w_qkv, e->w_att, e->w_mlp, B, T, position_ids, s));
   // last position of every (left-padded) row: row b*T + T-1  -> stride T*d
-  ORCCHK(head_and_sample(e, e->w_h + (size_t)(T - 1) * d, T * d, B, logits_out, s));
+  ORCCHK(head_and_sample(e, e->w_h + (size_t)(T - 1) * d, T * d, B, logits_out, false, s));
   return 0;
 }
 
 static int decode_one(orc_engine* e, const int32_t* forced, float* logits_out, hipStream_t s) {
   const orc_config& c = e->c;
   const int B = e->cur_batch;
-  HIPCHK(launch_embed_tokens(forced ? forced : e->d_next, e->embed, e->d_h, B, c.d_model, c.vocab, s));
-  ORCCHK(llama_layers(e, e->d_h, e->d_xn, e->d_qkv, e->d_att, e->d_mlp, B, 1, nullptr, true, s));
-  ORCCHK(head_and_sample(e, e->d_h, c.d_model, B, logits_out, s));
+  HIPCHK(launch_embed_tokens(forced ? forced : e->d_next, e->embed, e->d_h, B, c.d_model, c.vocab, e->d_ssq, c.d_model / 16, s));
+  ORCCHK(llama_decode_layers(e, B, s));
+  ORCCHK(head_and_sample(e, e->d_h, c.d_model, B, logits_out, true, s));
   return 0;
 }
 

@@ -5,7 +5,7 @@
 
 #include "common.h"
 
-enum { EPI_NONE = 0, EPI_QUICKGELU = 1, EPI_GELU = 2, EPI_RESIDUAL = 3, EPI_SWIGLU = 4, EPI_F32 = 5 };
+enum { EPI_NONE = 0, EPI_QUICKGELU = 1, EPI_GELU = 2, EPI_RESIDUAL = 3, EPI_SWIGLU = 4, EPI_F32 = 5, EPI_ROPE_KV = 6 };
 
 struct GemmArgs {
   const bf16_t* X; int ldx;   // activations [M][K] row-major
@@ -19,12 +19,31 @@ struct GemmArgs {
 hipError_t launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
 // decode-time skinny GEMM (M <= 16), same argument meaning; N multiple of 16 (32 for SWIGLU)
 hipError_t launch_gemv(const GemmArgs& a, int epi, hipStream_t s);
+// full argument set of the decode GEMV (fused rotary + KV-cache epilogue, sum-of-squares partials)
+struct GemvArgs {
+  const bf16_t* X; int ldx;
+  const bf16_t* Wp;
+  const bf16_t* bias;
+  const bf16_t* R; int ldr;
+  void* C; int ldc;
+  int M, N, K, Nvalid;
+  // EPI_RESIDUAL: when non-null, ssq_out[b * (N/16) + ntile] = sum of squares of the stored tile values of row b
+  float* ssq_out;
+  // EPI_ROPE_KV: W rows packed per head-section as (tile j, tile j+4) pairs; C = q output [M][H*128]
+  int H; const int* kbeg; const int* cur_len;
+  const bf16_t* cos_tab; const bf16_t* sin_tab; int maxpos;
+  bf16_t* Kc; bf16_t* Vc; long c_bs, c_hs;
+};
+hipError_t launch_gemv_ex(const GemvArgs& a, int epi, int variant, hipStream_t s);
 hipError_t launch_pack_weight(const bf16_t* W, int Nsrc, int K, const int* rowmap, bf16_t* Wp, int Np, int Kp,
                               hipStream_t s);
 
 // ---- norms
 hipError_t launch_rmsnorm(const bf16_t* x, int ldx, const bf16_t* w, bf16_t* y, int ldy, int rows, int d, float eps,
                           hipStream_t s);
+// RMSNorm with the row sums of squares supplied as n_part partials per row (part[row][n_part])
+hipError_t launch_rmsnorm_part(const bf16_t* x, int ldx, const float* part, int n_part, const bf16_t* w, bf16_t* y, int ldy,
+                               int rows, int d, float eps, hipStream_t s);
 hipError_t launch_layernorm(const bf16_t* x, int ldx, const bf16_t* w, const bf16_t* b, bf16_t* y, int ldy, int rows,
                             int d, float eps, hipStream_t s);
 
@@ -84,8 +103,9 @@ hipError_t launch_copy_rows(const bf16_t* src, long src_bs, bf16_t* dst, long ds
 // splice: out[r][:] = kind==0 ? 0 : table_kind[idx][:]   (code = kind<<28 | idx)
 hipError_t launch_gather_rows(const int* codes, const bf16_t* tok, const bf16_t* img, const bf16_t* desc, bf16_t* out,
                               int rows, int d, hipStream_t s);
+// out[r] = tok[ids[r]]; when ssq_part != null also part[r][0] = sum(out[r]^2), part[r][1..n_part) = 0
 hipError_t launch_embed_tokens(const int* ids, const bf16_t* tok, bf16_t* out, int rows, int d, int vocab,
-                               hipStream_t s);
+                               float* ssq_part, int n_part, hipStream_t s);
 hipError_t launch_view_reduce(const bf16_t* x, bf16_t* out, int B, int V, int n, int mode, hipStream_t s);
 hipError_t launch_pool2x2(const bf16_t* x, bf16_t* out, int n_img, int grid, int d, hipStream_t s);
 

@@ -150,11 +150,24 @@ __global__ __launch_bounds__(128) void gather_rows_kernel(const int* __restrict_
 }
 
 __global__ __launch_bounds__(128) void embed_tokens_kernel(const int* __restrict__ ids, const bf16_t* __restrict__ tok,
-                                                           bf16_t* __restrict__ out, int d, int vocab) {
+                                                           bf16_t* __restrict__ out, int d, int vocab,
+                                                           float* __restrict__ ssq_part, int n_part) {
+  __shared__ float sh[2];
   const int row = blockIdx.x;
   int id = ids[row];
   id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
-  for (int c = threadIdx.x; c < (d >> 3); c += 128) *(u32x4*)(out + (size_t)row * d + c * 8) = *(const u32x4*)(tok + (size_t)id * d + c * 8);
+  float ss = 0.f;
+  for (int c = threadIdx.x; c < (d >> 3); c += 128) {
+    const u32x4 v = *(const u32x4*)(tok + (size_t)id * d + c * 8);
+    *(u32x4*)(out + (size_t)row * d + c * 8) = v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ss += lo_bf(v[j]) * lo_bf(v[j]) + hi_bf(v[j]) * hi_bf(v[j]);
+  }
+  if (!ssq_part) return;
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  for (int t = threadIdx.x; t < n_part; t += 128) ssq_part[(size_t)row * n_part + t] = t == 0 ? sh[0] + sh[1] : 0.f;
 }
 
 // x (B, V, n) -> out (B, n): mode 0 = max over views, 1 = mean over views (fp32 sum, one rounding; torch mean)
@@ -285,9 +298,10 @@ hipError_t launch_gather_rows(const int* codes, const bf16_t* tok, const bf16_t*
   hipLaunchKernelGGL(gather_rows_kernel, dim3(rows), dim3(128), 0, s, codes, tok, img, desc, out, d);
   return hipGetLastError();
 }
-hipError_t launch_embed_tokens(const int* ids, const bf16_t* tok, bf16_t* out, int rows, int d, int vocab, hipStream_t s) {
+hipError_t launch_embed_tokens(const int* ids, const bf16_t* tok, bf16_t* out, int rows, int d, int vocab, float* ssq_part,
+                               int n_part, hipStream_t s) {
   if (rows <= 0) return hipSuccess;
-  hipLaunchKernelGGL(embed_tokens_kernel, dim3(rows), dim3(128), 0, s, ids, tok, out, d, vocab);
+  hipLaunchKernelGGL(embed_tokens_kernel, dim3(rows), dim3(128), 0, s, ids, tok, out, d, vocab, ssq_part, n_part);
   return hipGetLastError();
 }
 hipError_t launch_view_reduce(const bf16_t* x, bf16_t* out, int B, int V, int n, int mode, hipStream_t s) {

@@ -56,6 +56,34 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__
   }
 }
 
+// Decode-time RMSNorm whose reduction was done by the producer of x: sum(x^2) of row r = sum_t part[r][t]
+// (per-n-tile partials from the residual GEMV epilogue / the token-embedding gather, summed here in a fixed order).
+// grid (d / 1024, rows), 128 threads, 8 elements per thread: no row-wide reduction, many small workgroups.
+__global__ __launch_bounds__(128) void rmsnorm_part_kernel(const bf16_t* __restrict__ x, int ldx, const float* __restrict__ part,
+                                                           int n_part, const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
+                                                           int ldy, int d, float eps) {
+  __shared__ float sh[2];
+  const int row = blockIdx.y, c = blockIdx.x * 128 + threadIdx.x;
+  const bool ok = c * 8 < d;
+  u32x4 v = {0u, 0u, 0u, 0u}, wv = v;
+  if (ok) {
+    v = *(const u32x4*)(x + (size_t)row * ldx + c * 8);
+    wv = *(const u32x4*)(w + c * 8);
+  }
+  float ss = 0.f;
+  for (int t = threadIdx.x; t < n_part; t += 128) ss += part[(size_t)row * n_part + t];
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  const float r = rsqrtf((sh[0] + sh[1]) / (float)d + eps);
+  if (!ok) return;
+  u32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    o[j] = pack2(rbf(lo_bf(v[j]) * r) * lo_bf(wv[j]), rbf(hi_bf(v[j]) * r) * hi_bf(wv[j]));
+  *(u32x4*)(y + (size_t)row * ldy + c * 8) = o;
+}
+
 // y = bf16( (x - mean) * rstd * w + b ), biased variance, stats fp32 (torch.nn.LayerNorm on bf16)
 __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ w,
                                                         const bf16_t* __restrict__ b, bf16_t* __restrict__ y, int ldy,
@@ -119,6 +147,14 @@ hipError_t launch_rmsnorm(const bf16_t* x, int ldx, const bf16_t* w, bf16_t* y, 
   if (rows <= 0) return hipSuccess;
   if ((d & 7) || d > 8192) return hipErrorInvalidValue;
   hipLaunchKernelGGL(rmsnorm_kernel, dim3(rows), dim3(256), 0, s, x, ldx, w, y, ldy, d, eps);
+  return hipGetLastError();
+}
+
+hipError_t launch_rmsnorm_part(const bf16_t* x, int ldx, const float* part, int n_part, const bf16_t* w, bf16_t* y, int ldy,
+                               int rows, int d, float eps, hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  if ((d & 7) || n_part <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(rmsnorm_part_kernel, dim3((d + 1023) / 1024, rows), dim3(128), 0, s, x, ldx, part, n_part, w, y, ldy, d, eps);
   return hipGetLastError();
 }
 

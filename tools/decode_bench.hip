@@ -1,0 +1,204 @@
+// Micro-benchmark of the decode-step kernels (GPU box only; not part of the product or the tests).
+// Streams DISTINCT weights on every launch (pool >> 256 MiB Infinity Cache) so the numbers are HBM numbers.
+//   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/decode_bench tools/decode_bench.hip \
+//          oracle_amd/csrc/gemv.hip oracle_amd/csrc/attn.hip oracle_amd/csrc/norm.hip -DGEMV_ALL_VARIANTS
+//   run:   tools/decode_bench [M=8] [ctx=800]
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../oracle_amd/csrc/common.h"
+#include "../oracle_amd/csrc/kernels.h"
+
+#define CK(x)                                                                         \
+  do {                                                                                \
+    hipError_t e_ = (x);                                                              \
+    if (e_ != hipSuccess) {                                                           \
+      printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__);   \
+      exit(1);                                                                        \
+    }                                                                                 \
+  } while (0)
+
+// plain streaming read: the ceiling for "read B bytes once" at a given launch shape
+__global__ __launch_bounds__(512) void read_kernel(const u32x4* __restrict__ p, size_t n16, uint32_t* out) {
+  u32x4 acc = {0u, 0u, 0u, 0u};
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    const u32x4 a = __builtin_nontemporal_load(p + i), b = __builtin_nontemporal_load(p + i + stride);
+    const u32x4 c = __builtin_nontemporal_load(p + i + 2 * stride), d = __builtin_nontemporal_load(p + i + 3 * stride);
+    acc ^= a ^ b ^ c ^ d;
+  }
+  for (; i < n16; i += stride) acc ^= __builtin_nontemporal_load(p + i);
+  if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) out[0] = 1;
+}
+
+__global__ void fill_kernel(uint16_t* p, size_t n, uint32_t seed) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    uint32_t h = (uint32_t)i * 2654435761u + seed;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    // bf16 in about [-0.03, 0.03]: exponent 0x78..0x79
+    p[i] = (uint16_t)(((h & 1) << 15) | (0x3C00 + (h >> 8 & 0xFF)));
+  }
+}
+
+struct Shape { const char* name; int N, K, epi; };
+
+int main(int argc, char** argv) {
+  const int M = argc > 1 ? atoi(argv[1]) : 8;
+  const int ctx = argc > 2 ? atoi(argv[2]) : 800;
+  const int d = 4096, ff = 11008, H = 32;
+  const size_t pool_bytes = (size_t)3 << 30;
+  bf16_t* pool;
+  CK(hipMalloc((void**)&pool, pool_bytes));
+  hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, pool, pool_bytes / 2, 1u);
+  bf16_t *X, *Y, *R, *lnw, *cosb, *sinb;
+  float* ssq;
+  CK(hipMalloc((void**)&X, (size_t)16 * ff * 2));
+  CK(hipMalloc((void**)&Y, (size_t)16 * 32000 * 4));
+  CK(hipMalloc((void**)&R, (size_t)16 * ff * 2));
+  CK(hipMalloc((void**)&lnw, (size_t)ff * 2));
+  CK(hipMalloc((void**)&cosb, (size_t)4096 * 64 * 2));
+  CK(hipMalloc((void**)&sinb, (size_t)4096 * 64 * 2));
+  CK(hipMalloc((void**)&ssq, (size_t)16 * 4096 * 4));
+  hipLaunchKernelGGL(fill_kernel, dim3(256), dim3(256), 0, 0, X, (size_t)16 * ff, 2u);
+  hipLaunchKernelGGL(fill_kernel, dim3(256), dim3(256), 0, 0, R, (size_t)16 * ff, 3u);
+  hipLaunchKernelGGL(fill_kernel, dim3(256), dim3(256), 0, 0, lnw, (size_t)ff, 4u);
+  hipLaunchKernelGGL(fill_kernel, dim3(256), dim3(256), 0, 0, cosb, (size_t)4096 * 64, 5u);
+  hipLaunchKernelGGL(fill_kernel, dim3(256), dim3(256), 0, 0, sinb, (size_t)4096 * 64, 6u);
+  CK(hipMemset(ssq, 0, (size_t)16 * 4096 * 4));
+  // KV cache for the attention test + the rope epilogue: [B][H][Tmax][128]
+  const int Tmax = ctx + 64;
+  bf16_t *Kc, *Vc;
+  const size_t kv_elems = (size_t)16 * H * Tmax * 128;
+  CK(hipMalloc((void**)&Kc, kv_elems * 2 * 8));   // 8 "layers" to rotate through
+  CK(hipMalloc((void**)&Vc, kv_elems * 2 * 8));
+  hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, Kc, kv_elems * 8, 7u);
+  hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, Vc, kv_elems * 8, 8u);
+  int* ints;
+  CK(hipMalloc((void**)&ints, 64 * 4));
+  {
+    int h[64] = {0};
+    h[0] = ctx;                       // cur_len
+    CK(hipMemcpy(ints, h, sizeof(h), hipMemcpyHostToDevice));
+  }
+  float* part;
+  CK(hipMalloc((void**)&part, (size_t)16 * H * DECODE_NSPLIT * 130 * 4));
+  CK(hipDeviceSynchronize());
+
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  hipStream_t s = 0;
+  const int iters = 40;
+
+  auto time_it = [&](auto&& launch) -> float {
+    for (int i = 0; i < 3; ++i) launch(i);
+    CK(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) launch(i + 3);
+    CK(hipEventRecord(e1, s));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms * 1e3f / iters;
+  };
+
+  printf("M=%d ctx=%d  (us per launch incl. ~1.5us boundary; GB/s = algorithmic weight bytes / time)\n", M, ctx);
+  // ---- read ceiling
+  for (size_t mb : {33, 90, 100, 180}) {
+    const size_t bytes = mb << 20;
+    for (int grid : {256, 512, 1024, 2048}) {
+      float us = time_it([&](int i) {
+        const size_t off = ((size_t)i * bytes) % (pool_bytes - bytes);
+        hipLaunchKernelGGL(read_kernel, dim3(grid), dim3(512), 0, s, (const u32x4*)((char*)pool + (off & ~(size_t)255)), bytes / 16, (uint32_t*)Y);
+      });
+      printf("read %4zuMB grid %4d : %7.2f us  %7.1f GB/s\n", mb, grid, us, bytes / us * 1e-3);
+    }
+  }
+
+  const Shape shapes[] = {
+      {"qkv  ropekv    ", 3 * d, d, EPI_ROPE_KV},
+      {"o    residual  ", d, d, EPI_RESIDUAL},
+      {"gu   swiglu    ", 2 * ff, d, EPI_SWIGLU},
+      {"down residual  ", d, ff, EPI_RESIDUAL},
+      {"head f32       ", 32000, d, EPI_F32},
+  };
+  for (const Shape& sh : shapes) {
+    const size_t wbytes = (size_t)sh.N * sh.K * 2;
+    for (int variant = 0; variant <= 15; ++variant) {
+      GemvArgs a = {};
+      a.X = X; a.ldx = sh.K; a.bias = nullptr; a.R = R; a.ldr = sh.N; a.C = Y;
+      a.ldc = sh.epi == EPI_SWIGLU ? sh.N / 2 : (sh.epi == EPI_ROPE_KV ? d : sh.N);
+      a.M = M; a.N = sh.N; a.K = sh.K; a.Nvalid = sh.epi == EPI_SWIGLU ? sh.N / 2 : sh.N;
+      a.H = H; a.kbeg = ints + 16; a.cur_len = ints; a.cos_tab = cosb; a.sin_tab = sinb;
+      a.maxpos = 4096; a.Kc = Kc; a.Vc = Vc; a.c_bs = (long)H * Tmax * 128; a.c_hs = (long)Tmax * 128;
+      a.ssq_out = ssq;
+      hipError_t err = hipSuccess;
+      float us = time_it([&](int i) {
+        const size_t off = ((size_t)i * wbytes) % (pool_bytes - wbytes);
+        a.Wp = (const bf16_t*)((char*)pool + (off & ~(size_t)1023));
+        hipError_t e = launch_gemv_ex(a, sh.epi, variant, s);
+        if (e != hipSuccess) err = e;
+      });
+      if (err != hipSuccess) { printf("%s v%d : %s\n", sh.name, variant, hipGetErrorString(err)); (void)hipGetLastError(); continue; }
+      const int vi = variant - 1;
+      if (variant == 0) printf("%s default    : %7.2f us  %7.1f GB/s\n", sh.name, us, wbytes / us * 1e-3);
+      else printf("%s W%-2d U%d    : %7.2f us  %7.1f GB/s\n", sh.name, 1 << (vi / 3), variant == 15 ? 1 : 2 << (vi % 3), us, wbytes / us * 1e-3);
+    }
+  }
+  // ---- the two small norm launches
+  {
+    float us = time_it([&](int i) { CK(launch_rmsnorm_part(X, d, ssq, 256, lnw, R, d, M, d, 1e-5f, s)); });
+    printf("rmsnorm_part             : %7.2f us\n", us);
+    us = time_it([&](int i) { CK(launch_rmsnorm(X, d, lnw, R, d, M, d, 1e-5f, s)); });
+    printf("rmsnorm (self)           : %7.2f us\n", us);
+  }
+  // ---- decode attention
+  {
+    DecodeAttnArgs a;
+    a.Q = X; a.q_bs = d; a.c_bs = (long)H * Tmax * 128; a.c_hs = (long)Tmax * 128; a.O = Y; a.o_bs = d;
+    a.part = part; a.kbeg = ints + 16; a.cur_len = ints; a.B = M; a.H = H; a.scale = 0.0883883f;
+    const size_t bytes = (size_t)M * H * ctx * 512;
+    float us = time_it([&](int i) {
+      a.Kc = Kc + (size_t)(i % 8) * kv_elems;
+      a.Vc = Vc + (size_t)(i % 8) * kv_elems;
+      CK(launch_decode_attention(a, s));
+    });
+    printf("decode attention B=%d ctx=%d : %7.2f us  %7.1f GB/s\n", M, ctx, us, bytes / us * 1e-3);
+  }
+  // ---- one full layer sequence (7 launches), distinct weights per call
+  {
+    const size_t layer_bytes = ((size_t)4 * d * d + (size_t)3 * d * ff) * 2;
+    float us = time_it([&](int i) {
+      char* base = (char*)pool + ((size_t)(i % 6) * layer_bytes);
+      GemvArgs a = {};
+      a.bias = nullptr; a.M = M; a.H = H; a.kbeg = ints + 16; a.cur_len = ints;
+      a.cos_tab = cosb; a.sin_tab = sinb; a.maxpos = 4096; a.c_bs = (long)H * Tmax * 128; a.c_hs = (long)Tmax * 128;
+      a.Kc = Kc + (size_t)(i % 8) * kv_elems; a.Vc = Vc + (size_t)(i % 8) * kv_elems;
+      bf16_t* xn = R + (size_t)8 * ff;   // scratch rows
+      CK(launch_rmsnorm_part(X, d, ssq, 256, lnw, xn, d, M, d, 1e-5f, s));
+      a.X = xn; a.ldx = d; a.Wp = (const bf16_t*)base; a.C = Y; a.ldc = d; a.N = 3 * d; a.K = d; a.Nvalid = 3 * d; a.R = nullptr;
+      CK(launch_gemv_ex(a, EPI_ROPE_KV, 0, s));
+      DecodeAttnArgs t;
+      t.Q = Y; t.q_bs = d; t.Kc = a.Kc; t.Vc = a.Vc; t.c_bs = a.c_bs; t.c_hs = a.c_hs; t.O = R; t.o_bs = d;
+      t.part = part; t.kbeg = ints + 16; t.cur_len = ints; t.B = M; t.H = H; t.scale = 0.0883883f;
+      CK(launch_decode_attention(t, s));
+      a.X = R; a.Wp = (const bf16_t*)(base + (size_t)3 * d * d * 2); a.C = X; a.R = X; a.ldr = d; a.ldc = d; a.N = d; a.Nvalid = d;
+      a.ssq_out = ssq;
+      CK(launch_gemv_ex(a, EPI_RESIDUAL, 0, s));
+      CK(launch_rmsnorm_part(X, d, ssq, 256, lnw, xn, d, M, d, 1e-5f, s));
+      a.X = xn; a.Wp = (const bf16_t*)(base + (size_t)4 * d * d * 2); a.C = Y; a.ldc = ff; a.N = 2 * ff; a.Nvalid = ff; a.R = nullptr;
+      a.ssq_out = nullptr;
+      CK(launch_gemv_ex(a, EPI_SWIGLU, 0, s));
+      a.X = Y; a.ldx = ff; a.K = ff; a.Wp = (const bf16_t*)(base + ((size_t)4 * d * d + (size_t)2 * d * ff) * 2); a.C = X; a.R = X;
+      a.ldr = d; a.ldc = d; a.N = d; a.Nvalid = d; a.ssq_out = ssq;
+      CK(launch_gemv_ex(a, EPI_RESIDUAL, 0, s));
+    });
+    const size_t bytes = layer_bytes + (size_t)M * H * ctx * 512;
+    printf("full layer (7 launches)      : %7.2f us  %7.1f GB/s  -> %.2f ms / 32-layer step\n", us, bytes / us * 1e-3, us * 32e-3);
+  }
+  return 0;
+}
