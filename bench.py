@@ -89,6 +89,21 @@ def cpu_baseline(new_tokens, views, prompt_len_spliced):
             's_per_frame': per_frame}
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/: FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 x2 read correction already applied by
+    tools/pmc_summary; bench.py cannot run the profiler on itself). None when no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*', 'pmc_traffic_*.json')))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    for k, v in d['kernels'].items():
+        if 'gemv_kernel<2, 4,' in k:
+            return v['hbm_bytes_per_launch'], os.path.relpath(files[-1], ROOT)
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -192,6 +207,7 @@ def main():
         dec_ms = t_dec * 1e3 / max(a.new_tokens - 1, 1)
         ctx = T + a.new_tokens / 2
         dec_bytes = eng.decode_weight_bytes() + eng.kv_bytes_per_key() * ctx * a.batch
+        traffic, traffic_src = pmc_traffic()
         res = {
             'metric': 'scene graphs (frames)/sec whole node, 3-view LLaVA-7B bf16; p50 frame latency',
             'value': frames / elapsed, 'unit': 'frames/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
@@ -208,7 +224,8 @@ def main():
                             'frac_of_hbm_peak': dec_bytes / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
             'roofline': {'kernel': 'gemv_kernel<2,SWIGLU> (decode gate/up projection, 22016x4096 bf16 weights)', 'bound': 'hbm',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': None, 'launches_timed': prof_n, 'avg_launch_us': avg_us, 'algorithmic_bytes_per_launch': prof_bytes},
+                         'traffic': traffic, 'traffic_source': traffic_src, 'launches_timed': prof_n, 'avg_launch_us': avg_us,
+                         'algorithmic_bytes_per_launch': prof_bytes},
         }
         if world == 1 and not a.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(a.new_tokens, a.views, T)

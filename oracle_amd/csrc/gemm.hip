@@ -31,7 +31,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs a) {
   const int bid = blockIdx.x, nwg = gridDim.x;
   const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
   const int t = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
-  const int tm = t % MT, tn = t / MT;
+  // grouped raster inside the XCD's range: the ~64 tiles an XCD runs at once form an 8 (m) x 8 (n) block, so its L2
+  // serves 8 X panels + 8 W panels per k-step instead of a whole column of X panels (measured: 8.8 GB of fabric
+  // reads per 22016x4096 prefill launch with the column-major order, 30x the algorithmic bytes)
+  constexpr int GM = 8;
+  const int NTt = a.N >> 7;
+  const int grp = t / (GM * NTt), rin = t % (GM * NTt);
+  const int gm = (MT - grp * GM) < GM ? (MT - grp * GM) : GM;
+  const int tm = grp * GM + rin % gm, tn = rin / gm;
   const int m0 = tm << 7, n0 = tn << 7;
   const int KT = a.K >> 5;
   const int nk = a.K >> 6;
