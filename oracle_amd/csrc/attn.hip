@@ -146,7 +146,7 @@ __device__ __forceinline__ float rescale(float m_old, float m_new) {
 // 4 keys per wave-instruction = one contiguous 1 KiB read of the cache. With nsplit == 1 (enough (row, head) pairs to
 // fill the chip) the workgroup owns the whole key range and writes the bf16 output itself; otherwise partial
 // (m, l, acc) go to the workspace and decode_attn_combine_kernel merges them.
-template <int WAVES>
+template <int WAVES, int U>
 __global__ __launch_bounds__(WAVES * 64) void decode_attn_kernel(DecodeAttnArgs a) {
   __shared__ float sh_m[WAVES], sh_l[WAVES];
   __shared__ __attribute__((aligned(16))) float sh_acc[WAVES][128];
@@ -173,7 +173,6 @@ __global__ __launch_bounds__(WAVES * 64) void decode_attn_kernel(DecodeAttnArgs 
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 
-  constexpr int U = 4;
   for (int base = k_lo + w * 4; base < k_hi; base += 4 * WAVES * U) {
     u32x4 kv[U], vv[U];
     bool ok[U];
@@ -281,12 +280,28 @@ hipError_t launch_attention(const AttnArgs& a, int head_dim, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t launch_decode_attention(const DecodeAttnArgs& a, hipStream_t s) {
+hipError_t launch_decode_attention(const DecodeAttnArgs& a, hipStream_t s, int variant) {
   if (a.B <= 0) return hipSuccess;
-  if (a.B * a.H >= 192) {   // one workgroup of 16 waves per (row, head): fills the chip without a KV split
-    hipLaunchKernelGGL(decode_attn_kernel<16>, dim3(a.H, a.B, 1), dim3(1024), 0, s, a);
+  if (a.B * a.H >= 192) {   // one workgroup per (row, head) fills the chip without a KV split
+    switch (variant) {
+#ifdef GEMV_ALL_VARIANTS
+      case 1: hipLaunchKernelGGL((decode_attn_kernel<16, 4>), dim3(a.H, a.B, 1), dim3(1024), 0, s, a); break;
+      case 2: hipLaunchKernelGGL((decode_attn_kernel<16, 2>), dim3(a.H, a.B, 1), dim3(1024), 0, s, a); break;
+      case 3: hipLaunchKernelGGL((decode_attn_kernel<16, 1>), dim3(a.H, a.B, 1), dim3(1024), 0, s, a); break;
+      case 4: hipLaunchKernelGGL((decode_attn_kernel<8, 4>), dim3(a.H, a.B, 1), dim3(512), 0, s, a); break;
+      case 5: hipLaunchKernelGGL((decode_attn_kernel<8, 2>), dim3(a.H, a.B, 1), dim3(512), 0, s, a); break;
+      case 6: hipLaunchKernelGGL((decode_attn_kernel<8, 1>), dim3(a.H, a.B, 1), dim3(512), 0, s, a); break;
+      case 7: hipLaunchKernelGGL((decode_attn_kernel<4, 4>), dim3(a.H, a.B, 1), dim3(256), 0, s, a); break;
+      case 8: hipLaunchKernelGGL((decode_attn_kernel<4, 2>), dim3(a.H, a.B, 1), dim3(256), 0, s, a); break;
+      case 9: hipLaunchKernelGGL((decode_attn_kernel<4, 8>), dim3(a.H, a.B, 1), dim3(256), 0, s, a); break;
+      case 10: hipLaunchKernelGGL((decode_attn_kernel<2, 4>), dim3(a.H, a.B, 1), dim3(128), 0, s, a); break;
+      case 11: hipLaunchKernelGGL((decode_attn_kernel<2, 8>), dim3(a.H, a.B, 1), dim3(128), 0, s, a); break;
+#endif
+      // 16 waves, one 4-key step in flight per wave: deeper unrolls only oversubscribe the memory system (tools/decode_bench)
+      default: hipLaunchKernelGGL((decode_attn_kernel<16, 1>), dim3(a.H, a.B, 1), dim3(1024), 0, s, a); break;
+    }
   } else {
-    hipLaunchKernelGGL(decode_attn_kernel<4>, dim3(a.H, a.B, DECODE_NSPLIT), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((decode_attn_kernel<4, 4>), dim3(a.H, a.B, DECODE_NSPLIT), dim3(256), 0, s, a);
     hipLaunchKernelGGL(decode_attn_combine_kernel, dim3(a.H, a.B), dim3(128), 0, s, a);
   }
   return hipGetLastError();

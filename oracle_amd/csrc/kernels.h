@@ -75,7 +75,7 @@ struct DecodeAttnArgs {
   float scale;
 };
 #define DECODE_NSPLIT 4
-hipError_t launch_decode_attention(const DecodeAttnArgs& a, hipStream_t s);
+hipError_t launch_decode_attention(const DecodeAttnArgs& a, hipStream_t s, int variant = 0);
 
 // ---- rotary + KV-cache write. qkv [rows][3*H*128]; row = b*T + t; q rotated in place.
 struct RopeArgs {

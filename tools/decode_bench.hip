@@ -162,12 +162,14 @@ int main(int argc, char** argv) {
     a.Q = X; a.q_bs = d; a.c_bs = (long)H * Tmax * 128; a.c_hs = (long)Tmax * 128; a.O = Y; a.o_bs = d;
     a.part = part; a.kbeg = ints + 16; a.cur_len = ints; a.B = M; a.H = H; a.scale = 0.0883883f;
     const size_t bytes = (size_t)M * H * ctx * 512;
-    float us = time_it([&](int i) {
-      a.Kc = Kc + (size_t)(i % 8) * kv_elems;
-      a.Vc = Vc + (size_t)(i % 8) * kv_elems;
-      CK(launch_decode_attention(a, s));
-    });
-    printf("decode attention B=%d ctx=%d : %7.2f us  %7.1f GB/s\n", M, ctx, us, bytes / us * 1e-3);
+    for (int variant = 0; variant <= 11; ++variant) {
+      float us = time_it([&](int i) {
+        a.Kc = Kc + (size_t)(i % 8) * kv_elems;
+        a.Vc = Vc + (size_t)(i % 8) * kv_elems;
+        CK(launch_decode_attention(a, s, variant));
+      });
+      printf("decode attention B=%d ctx=%d v%d : %7.2f us  %7.1f GB/s\n", M, ctx, variant, us, bytes / us * 1e-3);
+    }
   }
   // ---- one full layer sequence (7 launches), distinct weights per call
   {
