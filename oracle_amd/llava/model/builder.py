@@ -3,8 +3,12 @@
 
 Offline there are no released weights, so two sources are supported:
   * 'synthetic[:tiny|:full][:seed=N][:chain]' -- random-init weights from oracle_amd/synth.py;
-  * a local directory holding `config.json` (LlavaConfig fields) and `*.safetensors` / `*.bin`-free weight
-    shards whose tensor names are the reference checkpoint keys (already LoRA-merged).
+  * a local directory holding `config.json` (LlavaConfig fields) and `*.safetensors` / `pytorch_model*.bin` weight
+    shards whose tensor names are the reference checkpoint keys (already LoRA-merged);
+  * the reference's released layout (builder.py:50-91): `model_path` = a LoRA checkpoint directory (`config.json`,
+    `adapter_config.json`, `adapter_model.bin`, `non_lora_trainables.bin`) whose name contains "lora", `model_base` = a
+    LOCAL directory with the base LLaVA weights, `mm_vision_tower` in the config = a LOCAL CLIP directory; the merge is
+    done by checkpoint.py (no peft).
 Hub names (e.g. 'liuhaotian/llava-v1.5-7b') cannot be fetched and raise a clear error."""
 import glob
 import json
@@ -50,17 +54,26 @@ def load_pretrained_model(model_path, model_base=None, model_name=None, load_8bi
         cfg = LlavaConfig(dims)
         tokenizer = SynthTokenizer(dims.vocab)
     elif os.path.isdir(model_path):
-        with open(os.path.join(model_path, 'config.json')) as f:
-            raw = json.load(f)
-        dims = Dims(**{k: raw[k] for k in Dims.__dataclass_fields__ if k in raw})
-        cfg = LlavaConfig(dims, **{k: v for k, v in raw.items() if k not in Dims.__dataclass_fields__})
-        from safetensors.torch import load_file
-        state = {}
-        for shard in sorted(glob.glob(os.path.join(model_path, '*.safetensors'))):
-            state.update(load_file(shard))
-        if os.path.exists(os.path.join(model_path, 'tokenizer.model')) or os.path.exists(os.path.join(model_path, 'tokenizer.json')):
+        from .checkpoint import assemble_state, dims_from_config, load_dir_state
+        lname = (model_name or name).lower()
+        if 'lora' in lname and model_base is not None:
+            # reference LoRA branch (builder.py:50-91): base + non_lora_trainables + merged adapter + CLIP + pooler
+            if not os.path.isdir(model_base):
+                raise FileNotFoundError(f'model_base {model_base!r} must be a local directory (hub downloads are unavailable offline)')
+            state, raw = assemble_state(model_path, model_base)
+            tok_dir = model_base
+        else:
+            with open(os.path.join(model_path, 'config.json')) as f:
+                raw = json.load(f)
+            state = load_dir_state(model_path)
+            tok_dir = model_path
+        dims = dims_from_config(raw)
+        skip = set(Dims.__dataclass_fields__) | {'vocab_size', 'hidden_size', 'num_hidden_layers', 'num_attention_heads',
+                                                 'intermediate_size', 'rms_norm_eps', 'rope_theta'}
+        cfg = LlavaConfig(dims, **{k: v for k, v in raw.items() if k not in skip})
+        if os.path.exists(os.path.join(tok_dir, 'tokenizer.model')) or os.path.exists(os.path.join(tok_dir, 'tokenizer.json')):
             from transformers import AutoTokenizer
-            tokenizer = AutoTokenizer.from_pretrained(model_path, use_fast=False)
+            tokenizer = AutoTokenizer.from_pretrained(tok_dir, use_fast=False)
         else:
             tokenizer = SynthTokenizer(dims.vocab)
     else:
