@@ -107,7 +107,15 @@ def gen_vision_full():
     with torch.inference_mode():
         vt = model.get_vision_tower()(imgs)
         feats = model.encode_images_pooled(imgs, [3])
-    save('vision_full_bfloat16', vt=sub2(vt, 19, 23), learned=sub2(feats, 19, 23))
+    # the same bf16-valued weights through the reference in fp32: measures the reference's own bf16 noise at full depth
+    model32, _ = rh.build_reference_model(d, st, dtype=torch.float32)
+    with torch.inference_mode():
+        vt32 = model32.get_vision_tower()(imgs.float())
+        feats32 = model32.encode_images_pooled(imgs.float(), [3])
+    out = dict(vt=sub2(vt, 19, 23), learned=sub2(feats, 19, 23))
+    out['vt']['sub_fp32'] = vt32[..., ::19, ::23].numpy()
+    out['learned']['sub_fp32'] = feats32[..., ::19, ::23].numpy()
+    save('vision_full_bfloat16', **out)
 
 
 def gen_splice():
@@ -183,6 +191,81 @@ def gen_llm(dtype_name):
         mine = cr.greedy_generate(st, TINY, ids, imgs, max_new_tokens=40)
         assert torch.equal(mine, gen), (tag, mine[:, ids.shape[1]:], gen[:, ids.shape[1]:])
     save(f'llm_tiny_{dtype_name}', **out)
+
+
+WIDE2 = Dims(n_layers=2, clip_layers=2)      # full-width LLaMA (4096 / 32 heads / 11008) x 2 layers, 2 CLIP layers
+
+
+def wide_prompts():
+    """Two left-padded rows at the plain-prompt scale (~190 text tokens -> T ~ 765) and one long row at the
+    temporal + symbolic-knowledge scale (BASELINE configs[3]: T ~ 2k)."""
+    g = torch.Generator().manual_seed(99)
+
+    def row(n_before, n_after):
+        a = torch.randint(3, 31999, (n_before,), generator=g)
+        b = torch.randint(3, 31999, (n_after,), generator=g)
+        a[a == 18610] = 18611
+        b[b == 18610] = 18611
+        return [1] + a.tolist() + [-200] + b.tolist()
+    r0, r1 = row(30, 160), row(30, 95)
+    L = max(len(r0), len(r1))
+    b2 = torch.tensor([[0] * (L - len(r)) + r for r in (r0, r1)])
+    long = torch.tensor([row(30, 1470)])
+    return b2, long
+
+
+def gen_llm_wide():
+    """Full-width LLaMA layers through the real reference in bf16: prefill logits and greedy tokens for a ragged
+    batch of 2 (configs[2] prompt scale) and for one ~2k-token row (configs[3] scale)."""
+    dtype = torch.bfloat16
+    st = synth_state(WIDE2, seed=11, dtype=dtype)
+    b2, long = wide_prompts()
+    out = {}
+    # the same bf16-valued weights through the reference in fp32: "exact math" logits, which measure the reference's own
+    # bf16 rounding noise at this width (the GPU test states its tolerance against that floor)
+    model32, _ = rh.build_reference_model(WIDE2, st, dtype=torch.float32)
+    for tag, ids in (('b2', b2), ('long', long)):
+        imgs = synth_images(ids.shape[0], 3, WIDE2, seed=555).float()
+        with torch.inference_mode():
+            mask0 = ids != 0
+            p_in = mask0.long().cumsum(-1) - 1
+            p_in.masked_fill_(~mask0, 1)
+            o = model32(input_ids=ids, attention_mask=mask0, position_ids=p_in, images=imgs, use_cache=True)
+        out[f'{tag}.logits_sub_fp32'] = o.logits[:, -1].float()[:, ::97].numpy()
+    del model32
+    model, cfg = rh.build_reference_model(WIDE2, st, dtype=dtype)
+    for tag, ids, views, n_new in (('b2', b2, 3, 8), ('long', long, 3, 4)):
+        imgs = synth_images(ids.shape[0], views, WIDE2, seed=555).to(dtype)
+        with torch.inference_mode():
+            mask0 = ids != 0
+            p_in = mask0.long().cumsum(-1) - 1
+            p_in.masked_fill_(~mask0, 1)
+            o = model(input_ids=ids, attention_mask=mask0, position_ids=p_in, images=imgs, use_cache=True)
+            logits = o.logits[:, -1].float()
+            top = torch.topk(logits, 16, dim=-1)
+        out[f'{tag}.ids'] = ids.numpy()
+        out[f'{tag}.top16_val'] = top.values.numpy()
+        out[f'{tag}.top16_idx'] = top.indices.numpy()
+        out[f'{tag}.logits_sub'] = logits[:, ::97].numpy()
+        out[f'{tag}.logits_absmax'] = logits.abs().max(-1).values.numpy()
+        gen = rh.reference_generate(model, cfg, ids, imgs, n_new)
+        out[f'{tag}.generated'] = gen.numpy()
+        mine = cr.greedy_generate(st, WIDE2, ids, imgs, max_new_tokens=n_new)
+        print(tag, 'reference tokens', gen[:, ids.shape[1]:].tolist(), 'restatement equal:', torch.equal(mine, gen))
+        assert torch.equal(mine, gen)
+    # peaked ("chain") weights at full width: free-running generate() must be token-identical, incl. ragged EOS / pad fill
+    del model
+    install_chain(st, WIDE2)
+    model, cfg = rh.build_reference_model(WIDE2, st, dtype=dtype)
+    ids = chain_prompts()
+    imgs = synth_images(3, 3, WIDE2, seed=556).to(dtype)
+    gen = rh.reference_generate(model, cfg, ids, imgs, 36)
+    mine = cr.greedy_generate(st, WIDE2, ids, imgs, max_new_tokens=36)
+    print('peak reference tokens', gen[:, ids.shape[1]:].tolist(), 'restatement equal:', torch.equal(mine, gen))
+    assert torch.equal(mine, gen)
+    out['peak.ids'] = ids.numpy()
+    out['peak.generated'] = gen.numpy()
+    save('llm_wide_bfloat16', **out)
 
 
 def chain_prompts():
@@ -261,6 +344,7 @@ ALL = {
     'splice': gen_splice,
     'llm_f32': lambda: gen_llm('float32'),
     'llm_bf16': lambda: gen_llm('bfloat16'),
+    'llm_wide': gen_llm_wide,
     'text': gen_text,
 }
 

@@ -1,0 +1,121 @@
+"""GPU parity at the BASELINE widths against golden vectors of the REAL reference (oracle/gen_golden.py: llm_wide,
+vision_full): full-width LLaMA layers (4096 / 32 heads / 11008, vocab 32000) on a ragged left-padded batch at the
+plain-prompt scale (configs[2], T ~ 765) and on one ~2k-token row (configs[3], temporal + symbolic-knowledge scale),
+and the full-depth (24-layer) CLIP tower + learned pooler + projector.
+Tolerance: the north_star's max rel err <= 1e-2 holds at the reduced sizes (test_engine_gpu.py). At full depth / width
+(23 residual CLIP layers; logits over the 32000-entry vocabulary) the reference's OWN bf16 rounding noise (its bf16 run against its fp32 run on the same bf16-valued weights,
+both stored in the golden file) is already 1.0-1.1e-2 of max|logit|, so two correct bf16 implementations cannot be
+expected to agree to 1e-2 in the max norm. Stated bar there: (i) GPU vs reference-bf16 <= 1.5 x that floor,
+(ii) GPU vs reference-fp32 <= 1.5 x that floor (the GPU is as close to exact math as the reference is), (iii) the
+reference's top-16 logits within the same band. Greedy tokens by the margin rule (a reference token may lose the
+argmax only inside the band)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-2
+
+
+@pytest.fixture(scope='module')
+def wide():
+    from oracle_amd.dims import Dims
+    from oracle_amd.engine import Engine
+    from oracle_amd.llava.model.language_model.llava_llama import LlavaConfig, LlavaLlamaForCausalLM
+    from oracle_amd.synth import synth_state
+    d = Dims(n_layers=2, clip_layers=2)
+    st = synth_state(d, seed=11)
+    eng = Engine(d, max_batch=2, max_seq=2176, max_images=6, max_new_tokens=16)
+    eng.load_state(st)
+    del st
+    model = LlavaLlamaForCausalLM(LlavaConfig(d, tokenizer_padding_side='left'), eng)
+    yield d, eng, model
+    eng.close()
+
+
+@pytest.mark.parametrize('tag', ['b2', 'long'])
+def test_full_width_llama_against_reference_golden(wide, tag):
+    from oracle_amd.synth import synth_images
+    d, eng, model = wide
+    g = np.load(os.path.join(GOLDEN, 'llm_wide_bfloat16.npz'))
+    ids = torch.from_numpy(g[f'{tag}.ids'])
+    imgs = synth_images(ids.shape[0], 3, d, seed=555)
+    mask = ids != 0
+    pos = mask.long().cumsum(-1) - 1
+    pos.masked_fill_(~mask, 1)
+    out = model(input_ids=ids.cuda(), attention_mask=mask.cuda(), position_ids=pos.cuda(), images=imgs.cuda(), use_cache=True)
+    logits = out.logits[:, -1].float().cpu()
+    absmax = torch.from_numpy(g[f'{tag}.logits_absmax'])
+    gold = torch.from_numpy(g[f'{tag}.logits_sub'])
+    exact = torch.from_numpy(g[f'{tag}.logits_sub_fp32'])
+    floor = ((gold - exact).abs().max(-1).values / absmax).max().item()        # the reference's own bf16 noise
+    band = 1.5 * max(floor, TOL / 1.5)
+    err = ((logits[:, ::97] - gold).abs().max(-1).values / absmax).max().item()
+    err_exact = ((logits[:, ::97] - exact).abs().max(-1).values / absmax).max().item()
+    print(f'{tag}: reference bf16 noise floor {floor:.4f}, GPU vs reference {err:.4f}, GPU vs fp32 math {err_exact:.4f}')
+    assert err <= band, (err, floor)
+    assert err_exact <= band, (err_exact, floor)
+    # the reference's 16 best tokens keep their values
+    idx = torch.from_numpy(g[f'{tag}.top16_idx'])
+    val = torch.from_numpy(g[f'{tag}.top16_val'])
+    assert ((logits.gather(1, idx) - val).abs().max(-1).values / absmax).max().item() <= band
+    # teacher-forced greedy decode along the reference's tokens: each reference token is the argmax up to the band
+    new = torch.from_numpy(g[f'{tag}.generated'])[:, ids.shape[1]:]
+    cur = logits
+    for step in range(new.shape[1]):
+        tok = new[:, step]
+        band = 2 * TOL * cur.abs().max(-1).values
+        assert bool((cur.gather(1, tok[:, None])[:, 0] >= cur.max(-1).values - band).all()), (tag, step)
+        cur = eng.decode_step(tok.cuda(), want_logits=True).float().cpu()
+
+
+def test_full_width_generate_is_token_identical_on_peaked_weights():
+    """Free-running greedy generate() through the mirrored API at full LLaMA width reproduces the real reference's
+    tokens exactly (rows finish at different steps: EOS, then pad fill)."""
+    from oracle_amd.dims import Dims
+    from oracle_amd.engine import Engine
+    from oracle_amd.llava.model.language_model.llava_llama import LlavaConfig, LlavaLlamaForCausalLM
+    from oracle_amd.synth import install_chain, synth_images, synth_state
+    d = Dims(n_layers=2, clip_layers=2)
+    st = install_chain(synth_state(d, seed=11), d)
+    eng = Engine(d, max_batch=3, max_seq=704, max_images=9, max_new_tokens=48)
+    eng.load_state(st)
+    del st
+    model = LlavaLlamaForCausalLM(LlavaConfig(d, tokenizer_padding_side='left'), eng)
+    g = np.load(os.path.join(GOLDEN, 'llm_wide_bfloat16.npz'))
+    ids = torch.from_numpy(g['peak.ids'])
+    imgs = synth_images(3, 3, d, seed=556)
+    out = model.generate(ids.cuda(), images=imgs.cuda(), do_sample=False, use_cache=True, max_new_tokens=36).cpu()
+    ref = torch.from_numpy(g['peak.generated'])
+    assert torch.equal(out, ref), (out[:, ids.shape[1]:], ref[:, ids.shape[1]:])
+    eng.close()
+
+
+def test_full_depth_clip_pooler_projector_against_reference_golden():
+    from oracle_amd.dims import Dims
+    from oracle_amd.engine import Engine
+    from oracle_amd.llava.model.language_model.llava_llama import LlavaConfig, LlavaLlamaForCausalLM
+    from oracle_amd.synth import synth_images, synth_state
+    d = Dims(n_layers=1, d_model=512, n_heads=4, d_ff=1408)          # 24-layer CLIP; the LLaMA part is not used
+    st = synth_state(d, seed=3)
+    eng = Engine(d, max_batch=1, max_seq=640, max_images=3, max_new_tokens=16)
+    eng.load_state(st)
+    model = LlavaLlamaForCausalLM(LlavaConfig(d, tokenizer_padding_side='left'), eng)
+    g = np.load(os.path.join(GOLDEN, 'vision_full_bfloat16.npz'))
+    imgs = synth_images(1, 3, d, seed=4321)[0].cuda()
+    def check(x, key):
+        assert list(x.shape) == list(g[f'{key}.shape'])
+        gold, exact, absmax = torch.from_numpy(g[f'{key}.sub']), torch.from_numpy(g[f'{key}.sub_fp32']), float(g[f'{key}.absmax'])
+        floor = float((gold - exact).abs().max()) / absmax              # the reference's own bf16 noise after 23 layers
+        band = 1.5 * max(floor, TOL / 1.5)
+        err = float((x[..., ::19, ::23] - gold).abs().max()) / absmax
+        err_exact = float((x[..., ::19, ::23] - exact).abs().max()) / absmax
+        print(f'{key}: reference bf16 noise floor {floor:.4f}, GPU vs reference {err:.4f}, GPU vs fp32 math {err_exact:.4f}')
+        assert err <= band and err_exact <= band, (err, err_exact, floor)
+    check(eng.vision_encode(imgs).float().cpu(), 'vt')
+    check(model.encode_images_pooled(imgs, [3]).float().cpu(), 'learned')
+    eng.close()
