@@ -105,3 +105,27 @@ def test_llm_logits_and_tokens(dtype_name, tol):
         if tag == 'peak' or dtype_name == 'float32':
             out = cr.greedy_generate(st, TINY, ids, imgs, max_new_tokens=40, image_features=feats)
             assert np.array_equal(out.numpy(), g[f'{tag}.generated'])
+
+
+def test_full_width_llama_and_full_depth_clip():
+    """The restatement at the BASELINE widths against the real reference's goldens (llm_wide, vision_full): bf16 on the
+    same machine class reproduces the reference bit for bit on the stored subsets (gen_golden asserted token equality)."""
+    g = _load('llm_wide_bfloat16.npz')
+    d = Dims(n_layers=2, clip_layers=2)
+    st = synth_state(d, seed=11)
+    ids = torch.from_numpy(g['b2.ids'])
+    imgs = synth_images(2, 3, d, seed=555)
+    with torch.inference_mode():
+        feats = cr.encode_image_features(st, d, imgs, 'learned')
+        emb, mask, pos, _ = cr.splice(st, ids, ids != 0, feats)
+        logits, _ = cr.llama_forward(st, d, emb, mask, pos)
+    ref = torch.from_numpy(g['b2.logits_sub'])
+    assert float((logits.float()[:, ::97] - ref).abs().max() / ref.abs().max()) <= 1e-2
+    assert np.array_equal(logits.float().topk(1).indices[:, 0].numpy(), g['b2.top16_idx'][:, 0])
+    del st
+    gv = _load('vision_full_bfloat16.npz')
+    dv = Dims(n_layers=1, d_model=512, n_heads=4, d_ff=1408)
+    stv = synth_state(dv, seed=3, only=None)
+    with torch.inference_mode():
+        vt = cr.vision_tower(stv, dv, synth_images(1, 3, dv, seed=4321)[0])
+    _close(vt, gv, 'vt', 19, 23, 1e-2)
