@@ -280,7 +280,7 @@ extern "C" int orc_engine_finalize(orc_engine* e) {
   {
     const std::string p = "model.vision_tower.vision_tower.vision_model.";
     const int kpatch = 3 * c.clip_patch * c.clip_patch;
-    ORCCHK(pack_rows(e, {p + "embeddings.patch_embedding.weight"}, kpatch, nullptr, 128, &e->patch_w));
+    ORCCHK(pack_rows(e, {p + "embeddings.patch_embedding.weight"}, kpatch, nullptr, 256, &e->patch_w));
     free_raw(e, {p + "embeddings.patch_embedding.weight"});
     const int tokens = (c.clip_image / c.clip_patch) * (c.clip_image / c.clip_patch) + 1;
     ORCCHK(take(e, p + "embeddings.class_embedding", &e->clip_cls, c.clip_d));
@@ -299,13 +299,13 @@ extern "C" int orc_engine_finalize(orc_engine* e) {
       ORCCHK(take(e, q + "layer_norm2.weight", &L.ln2w, c.clip_d));
       ORCCHK(take(e, q + "layer_norm2.bias", &L.ln2b, c.clip_d));
       std::vector<std::string> w3 = {q + "self_attn.q_proj.weight", q + "self_attn.k_proj.weight", q + "self_attn.v_proj.weight"};
-      ORCCHK(pack_rows(e, w3, c.clip_d, nullptr, 128, &L.qkv));
+      ORCCHK(pack_rows(e, w3, c.clip_d, nullptr, 256, &L.qkv));
       ORCCHK(concat_vec(e, {q + "self_attn.q_proj.bias", q + "self_attn.k_proj.bias", q + "self_attn.v_proj.bias"}, &L.bqkv, 128));
-      ORCCHK(pack_rows(e, {q + "self_attn.out_proj.weight"}, c.clip_d, nullptr, 128, &L.o));
+      ORCCHK(pack_rows(e, {q + "self_attn.out_proj.weight"}, c.clip_d, nullptr, 256, &L.o));
       ORCCHK(take(e, q + "self_attn.out_proj.bias", &L.bo, c.clip_d));
-      ORCCHK(pack_rows(e, {q + "mlp.fc1.weight"}, c.clip_d, nullptr, 128, &L.fc1));
+      ORCCHK(pack_rows(e, {q + "mlp.fc1.weight"}, c.clip_d, nullptr, 256, &L.fc1));
       ORCCHK(take(e, q + "mlp.fc1.bias", &L.b1, c.clip_ff));
-      ORCCHK(pack_rows(e, {q + "mlp.fc2.weight"}, c.clip_ff, nullptr, 128, &L.fc2));
+      ORCCHK(pack_rows(e, {q + "mlp.fc2.weight"}, c.clip_ff, nullptr, 256, &L.fc2));
       ORCCHK(take(e, q + "mlp.fc2.bias", &L.b2, c.clip_d));
       w3.push_back(q + "self_attn.out_proj.weight");
       w3.push_back(q + "mlp.fc1.weight");
@@ -333,15 +333,15 @@ extern "C" int orc_engine_finalize(orc_engine* e) {
       const std::string q = buf;
       PoolLayer& L = e->pool[i];
       std::vector<std::string> w3 = {q + "attention.self.query.weight", q + "attention.self.key.weight", q + "attention.self.value.weight"};
-      ORCCHK(pack_rows(e, w3, c.clip_d, nullptr, 128, &L.qkv));
+      ORCCHK(pack_rows(e, w3, c.clip_d, nullptr, 256, &L.qkv));
       ORCCHK(concat_vec(e, {q + "attention.self.query.bias", q + "attention.self.key.bias", q + "attention.self.value.bias"}, &L.bqkv, 128));
-      ORCCHK(pack_rows(e, {q + "attention.output.dense.weight"}, c.clip_d, nullptr, 128, &L.o));
+      ORCCHK(pack_rows(e, {q + "attention.output.dense.weight"}, c.clip_d, nullptr, 256, &L.o));
       ORCCHK(take(e, q + "attention.output.dense.bias", &L.bo, c.clip_d));
       ORCCHK(take(e, q + "attention.output.LayerNorm.weight", &L.ln1w, c.clip_d));
       ORCCHK(take(e, q + "attention.output.LayerNorm.bias", &L.ln1b, c.clip_d));
-      ORCCHK(pack_rows(e, {q + "intermediate.dense.weight"}, c.clip_d, nullptr, 128, &L.wi));
+      ORCCHK(pack_rows(e, {q + "intermediate.dense.weight"}, c.clip_d, nullptr, 256, &L.wi));
       ORCCHK(take(e, q + "intermediate.dense.bias", &L.bi, c.pool_ff));
-      ORCCHK(pack_rows(e, {q + "output.dense.weight"}, c.pool_ff, nullptr, 128, &L.wout));
+      ORCCHK(pack_rows(e, {q + "output.dense.weight"}, c.pool_ff, nullptr, 256, &L.wout));
       ORCCHK(take(e, q + "output.dense.bias", &L.bout, c.clip_d));
       ORCCHK(take(e, q + "output.LayerNorm.weight", &L.ln2w, c.clip_d));
       ORCCHK(take(e, q + "output.LayerNorm.bias", &L.ln2b, c.clip_d));
@@ -355,15 +355,15 @@ extern "C" int orc_engine_finalize(orc_engine* e) {
     }
   }
   // ---------------- projector
-  ORCCHK(pack_rows(e, {"model.mm_projector.0.weight"}, c.clip_d, nullptr, 128, &e->proj0));
+  ORCCHK(pack_rows(e, {"model.mm_projector.0.weight"}, c.clip_d, nullptr, 256, &e->proj0));
   ORCCHK(take(e, "model.mm_projector.0.bias", &e->proj_b0, c.d_model));
-  ORCCHK(pack_rows(e, {"model.mm_projector.2.weight"}, c.d_model, nullptr, 128, &e->proj2));
+  ORCCHK(pack_rows(e, {"model.mm_projector.2.weight"}, c.d_model, nullptr, 256, &e->proj2));
   ORCCHK(take(e, "model.mm_projector.2.bias", &e->proj_b2, c.d_model));
   free_raw(e, {"model.mm_projector.0.weight", "model.mm_projector.2.weight"});
   // ---------------- LLaMA
   ORCCHK(take(e, "model.embed_tokens.weight", &e->embed, (size_t)c.vocab * c.d_model));
   ORCCHK(take(e, "model.norm.weight", &e->final_norm, c.d_model));
-  ORCCHK(pack_rows(e, {"lm_head.weight"}, c.d_model, nullptr, 128, &e->lm_head));
+  ORCCHK(pack_rows(e, {"lm_head.weight"}, c.d_model, nullptr, 256, &e->lm_head));
   free_raw(e, {"lm_head.weight"});
   e->llama.resize(c.n_layers);
   std::vector<int> gu_map(2 * c.d_ff);
@@ -385,12 +385,12 @@ extern "C" int orc_engine_finalize(orc_engine* e) {
     ORCCHK(take(e, q + "input_layernorm.weight", &L.ln_in, c.d_model));
     ORCCHK(take(e, q + "post_attention_layernorm.weight", &L.ln_post, c.d_model));
     std::vector<std::string> w3 = {q + "self_attn.q_proj.weight", q + "self_attn.k_proj.weight", q + "self_attn.v_proj.weight"};
-    ORCCHK(pack_rows(e, w3, c.d_model, nullptr, 128, &L.qkv));
-    ORCCHK(pack_rows(e, w3, c.d_model, &qkv_dec_map, 128, &L.qkv_dec));
-    ORCCHK(pack_rows(e, {q + "self_attn.o_proj.weight"}, c.d_model, nullptr, 128, &L.o));
+    ORCCHK(pack_rows(e, w3, c.d_model, nullptr, 256, &L.qkv));
+    ORCCHK(pack_rows(e, w3, c.d_model, &qkv_dec_map, 256, &L.qkv_dec));
+    ORCCHK(pack_rows(e, {q + "self_attn.o_proj.weight"}, c.d_model, nullptr, 256, &L.o));
     std::vector<std::string> w2 = {q + "mlp.gate_proj.weight", q + "mlp.up_proj.weight"};
-    ORCCHK(pack_rows(e, w2, c.d_model, &gu_map, 128, &L.gu));
-    ORCCHK(pack_rows(e, {q + "mlp.down_proj.weight"}, c.d_ff, nullptr, 128, &L.down));
+    ORCCHK(pack_rows(e, w2, c.d_model, &gu_map, 256, &L.gu));
+    ORCCHK(pack_rows(e, {q + "mlp.down_proj.weight"}, c.d_ff, nullptr, 256, &L.down));
     w3.push_back(q + "self_attn.o_proj.weight");
     w3.push_back(w2[0]);
     w3.push_back(w2[1]);
@@ -799,7 +799,7 @@ extern "C" int64_t orc_kv_bytes_per_key(orc_engine* e) { return (int64_t)2 * 2 *
 extern "C" int orc_test_gemm(const void* x, int M, int K, const void* w, int N, const void* bias, const void* residual,
                              int epi, int use_gemv, void* out, void* stream) {
   hipStream_t s = S(stream);
-  const int Np = round_up(N, 128), Kp = round_up(K, 64);
+  const int Np = round_up(N, 256), Kp = round_up(K, 64);
   if (Kp != K) return fail("orc_test_gemm", "K must be a multiple of 64");
   bf16_t* wp;
   HIPCHK(hipMalloc((void**)&wp, (size_t)Np * Kp * 2));
@@ -818,7 +818,10 @@ extern "C" int orc_test_gemm(const void* x, int M, int K, const void* w, int N, 
   a.X = (const bf16_t*)x; a.ldx = K; a.Wp = wp; a.bias = (const bf16_t*)bias; a.R = (const bf16_t*)residual;
   const int nout = epi == EPI_SWIGLU ? N / 2 : N;
   a.ldr = nout; a.C = out; a.ldc = nout; a.M = M; a.N = Np; a.K = Kp; a.Nvalid = nout;
-  hipError_t err = use_gemv ? launch_gemv(a, epi, s) : launch_gemm(a, epi, s);
+  // use_gemv: 0 = GEMM (automatic kernel choice), 1 = decode GEMV, 2 = 128^2 register-staged GEMM, 3 / 4 = LDS-DMA GEMM BM 256 / 128
+  if (use_gemv >= 2) gemm_force_kernel(use_gemv - 1);
+  hipError_t err = use_gemv == 1 ? launch_gemv(a, epi, s) : launch_gemm(a, epi, s);
+  gemm_force_kernel(0);
   if (err != hipSuccess) return fail("orc_test_gemm", hipGetErrorString(err));
   HIPCHK(hipStreamSynchronize(s));
   HIPCHK(hipFree(wp));

@@ -17,7 +17,10 @@
 
 namespace {
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+int g_gemm_force = 0;   // tools: 0 auto, 1 = 128^2 register-staged kernel, 2 / 3 = DMA kernel with BM 256 / 128
+
+// fp32 sigmoid on the hardware exp / rcp (about 1 ulp each): every use rounds the result to bf16 right away
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs a) {
@@ -171,6 +174,194 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Large-M GEMM (prefill, ViT, pooler, projector): BM x 256 x 64 tiles, 8 waves (2 along m x 4 along n, each
+// (BM/2) x 64), one workgroup per CU. Both operands go global -> LDS by LDS-DMA (global_load_lds, 16 B per lane, no
+// VGPR staging and no ds_write: the 128^2 register-staged kernel above is bound by its ds_write_b128 + ds_read traffic,
+// 1.3 LDS cycles per MFMA cycle), two 64 KiB stages:
+//     wait my DMA of stage s -> barrier -> issue the DMA of tile k+1 into stage s^1 -> MFMAs on stage s
+// so a tile's loads fly during the whole previous k-step (~2k MFMA cycles per SIMD).
+// W blocks are already in fragment order: one DMA instruction = one 1-KiB block = a conflict-free ds_read_b128 image.
+// X rows land as 128-B rows whose 16-B chunks are XOR-swizzled; LDS-DMA destinations are lane-linear, so the swizzle
+// is applied to the per-lane SOURCE address (each instruction still reads 8 whole 128-B lines).
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+
+template <int BM, int EPI>
+__global__ __launch_bounds__(512) void gemm_dma_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int XB = BM * 128;              // bytes of the X part of a stage
+  constexpr int STAGE = XB + 256 * 128;     // + W part
+  constexpr int MTW = BM / 32;              // 16-row m-tiles per wave
+  constexpr int XI = BM / 64;               // X DMA instructions per wave per stage (8 rows each)
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w >> 2, wn = w & 3;
+  const int g = lane >> 4, r16 = lane & 15;
+
+  const int MT = (a.M + BM - 1) / BM, NTt = a.N >> 8;
+  const int bid = blockIdx.x, nwg = gridDim.x;
+  const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
+  const int t = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+  constexpr int GM = 4;                     // 32 tiles run per XCD at once: 4 (m) x 8 (n)
+  const int grp = t / (GM * NTt), rin = t % (GM * NTt);
+  const int gm = (MT - grp * GM) < GM ? (MT - grp * GM) : GM;
+  const int tm = grp * GM + rin % gm, tn = rin / gm;
+  const int m0 = tm * BM, n0 = tn << 8;
+  const int KT = a.K >> 5, nk = a.K >> 6;
+
+  // per-lane DMA sources
+  const bf16_t* xsrc[XI];
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int row = (i * 8 + w) * 8 + (lane >> 3);          // row inside the tile; LDS image is lane-linear: [row][chunk']
+    int grow = m0 + row;
+    grow = grow < a.M ? grow : a.M - 1;
+    xsrc[i] = a.X + (size_t)grow * a.ldx + (((lane & 7) ^ (row & 7)) << 3);
+  }
+  const bf16_t* wsrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int b = i * 8 + w;                                  // block b = (n-tile b>>1, k-tile b&1)
+    wsrc[i] = a.Wp + ((size_t)((n0 >> 4) + (b >> 1)) * KT + (b & 1)) * 512 + lane * 8;
+  }
+  auto dma = [&](int kt64, int stage) {
+    char* sx = smem + stage * STAGE;
+    char* sw = sx + XB;
+#pragma unroll
+    for (int i = 0; i < XI; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(xsrc[i] + kt64 * 64), (lds_void_t*)(sx + (i * 8 + w) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(wsrc[i] + (size_t)kt64 * 1024), (lds_void_t*)(sw + (i * 8 + w) * 1024), 16, 0, 0);
+  };
+
+  f32x4 acc[4][MTW];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < MTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  dma(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int st = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // my DMA of this stage has landed
+    __syncthreads();                                          // everyone's has, and everyone left the other stage
+    if (kt + 1 < nk) dma(kt + 1, st ^ 1);
+    const char* sx = smem + st * STAGE;
+    const char* sw = sx + XB;
+    // W fragments of the whole k-step stay in registers; X fragments stream one 16-row m-tile at a time, the next
+    // m-tile's two reads issued ahead of the current tile's 8 MFMAs (register double buffer)
+    bf16x8 wf[2][4];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) wf[kk][nt] = *(const bf16x8*)(sw + ((((wn * 4 + nt) << 1) + kk) << 10) + lane * 16);
+    auto xread = [&](int mt, int kk) -> bf16x8 {
+      const int row = wm * (BM / 2) + mt * 16 + r16;
+      return *(const bf16x8*)(sx + row * 128 + (((kk * 4 + g) ^ (row & 7)) << 4));
+    };
+    bf16x8 xc[2] = {xread(0, 0), xread(0, 1)};
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+      bf16x8 xn[2] = {xc[0], xc[1]};
+      if (mt + 1 < MTW) { xn[0] = xread(mt + 1, 0); xn[1] = xread(mt + 1, 1); }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][nt], xc[kk], acc[nt][mt], 0, 0, 0);
+      xc[0] = xn[0]; xc[1] = xn[1];
+    }
+  }
+
+  // ---- epilogue (same rounding points as gemm_bf16_kernel). bf16 outputs are transposed through LDS (each wave its own
+  // (BM/2) x 64 tile, rows padded to 144 B) so global stores and the residual loads are whole 128-B lines, 16 B per lane,
+  // instead of 8-B fragments of 16 different rows.
+  if constexpr (EPI == EPI_F32) {
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+      const int m = m0 + wm * (BM / 2) + mt * 16 + r16;
+      if (m >= a.M) continue;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + wn * 64 + nt * 16 + 4 * g;
+        if (n >= a.Nvalid) continue;
+        float b[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias) {
+          const u32x2 bv = *(const u32x2*)(a.bias + n);
+          b[0] = lo_bf(bv[0]); b[1] = hi_bf(bv[0]); b[2] = lo_bf(bv[1]); b[3] = hi_bf(bv[1]);
+        }
+        *(f32x4*)((float*)a.C + (size_t)m * a.ldc + n) =
+            f32x4{rbf(acc[nt][mt][0] + b[0]), rbf(acc[nt][mt][1] + b[1]), rbf(acc[nt][mt][2] + b[2]), rbf(acc[nt][mt][3] + b[3])};
+      }
+    }
+  } else {
+    constexpr int ROWB = 144;
+    constexpr int WCOLS = EPI == EPI_SWIGLU ? 32 : 64;        // output columns of this wave's tile
+    __syncthreads();                                          // every wave has left the stage buffers
+    char* tile = smem + w * (BM / 2) * ROWB;
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+      const int ml = mt * 16 + r16;
+      if constexpr (EPI == EPI_SWIGLU) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          float o[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float gt = rbf(acc[2 * p][mt][r]);
+            const float up = rbf(acc[2 * p + 1][mt][r]);
+            const float sg = rbf(gt * sigmoidf_(gt));
+            o[r] = sg * up;
+          }
+          *(u32x2*)(tile + ml * ROWB + (p * 16 + 4 * g) * 2) = u32x2{pack2(o[0], o[1]), pack2(o[2], o[3])};
+        }
+      } else {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const int n = n0 + wn * 64 + nt * 16 + 4 * g;
+          float y[4];
+          float b[4] = {0.f, 0.f, 0.f, 0.f};
+          if (a.bias && n < a.Nvalid) {
+            const u32x2 bv = *(const u32x2*)(a.bias + n);
+            b[0] = lo_bf(bv[0]); b[1] = hi_bf(bv[0]); b[2] = lo_bf(bv[1]); b[3] = hi_bf(bv[1]);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) y[r] = rbf(acc[nt][mt][r] + b[r]);
+          if constexpr (EPI == EPI_QUICKGELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float t1 = rbf(1.702f * y[r]);
+              const float sg = rbf(sigmoidf_(t1));
+              y[r] = y[r] * sg;
+            }
+          } else if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = 0.5f * y[r] * (1.0f + erff(y[r] * 0.70710678118654752440f));
+          }
+          *(u32x2*)(tile + ml * ROWB + (nt * 16 + 4 * g) * 2) = u32x2{pack2(y[0], y[1]), pack2(y[2], y[3])};
+        }
+      }
+    }
+    // rows of the tile back out: 16 B per lane, a wave instruction = (64 / (WCOLS / 8)) rows x one whole row segment
+    constexpr int CPR = WCOLS / 8;                             // 16-B chunks per row
+    const int ncol0 = (EPI == EPI_SWIGLU ? (n0 >> 1) + wn * 32 : n0 + wn * 64) + (lane % CPR) * 8;
+#pragma unroll
+    for (int it = 0; it < (BM / 2) * CPR / 64; ++it) {
+      const int ml = it * (64 / CPR) + lane / CPR;
+      const int m = m0 + wm * (BM / 2) + ml;
+      if (m >= a.M || ncol0 >= a.Nvalid) continue;
+      u32x4 v = *(const u32x4*)(tile + ml * ROWB + (lane % CPR) * 16);
+      if constexpr (EPI == EPI_RESIDUAL) {
+        const u32x4 rv = *(const u32x4*)(a.R + (size_t)m * a.ldr + ncol0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = pack2(lo_bf(v[j]) + lo_bf(rv[j]), hi_bf(v[j]) + hi_bf(rv[j]));
+      }
+      *(u32x4*)((bf16_t*)a.C + (size_t)m * a.ldc + ncol0) = v;
+    }
+  }
+}
+
 // W[Nsrc][K] row-major (optionally through rowmap: packed row -> source row, -1 = zero row)
 // -> packed blocks [Np/16][Kp/32][64 lanes][8].
 __global__ void pack_weight_kernel(const bf16_t* __restrict__ W, int Nsrc, int K, const int* __restrict__ rowmap,
@@ -195,8 +386,33 @@ __global__ void pack_weight_kernel(const bf16_t* __restrict__ W, int Nsrc, int K
   }
 }
 
+template <int BM, int EPI>
+hipError_t launch_dma_t(const GemmArgs& a, hipStream_t s) {
+  static bool attr_set = false;
+  constexpr int stages = 2 * (BM * 128 + 256 * 128), epi = 8 * (BM / 2) * 144;
+  constexpr int lds = stages > epi ? stages : epi;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<BM, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int MT = (a.M + BM - 1) / BM, NT = a.N / 256;
+  hipLaunchKernelGGL((gemm_dma_kernel<BM, EPI>), dim3(MT * NT), dim3(512), lds, s, a);
+  return hipGetLastError();
+}
+
 template <int EPI>
 hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
+  if ((a.M > 128 || g_gemm_force >= 2) && (a.N & 255) == 0 && g_gemm_force != 1) {
+    // tile height by whole-chip rounds: work done / work paid for over ceil(tiles / 256 CUs) rounds
+    auto eff = [&](int bm) {
+      const long tiles = (long)((a.M + bm - 1) / bm) * (a.N / 256);
+      const long rounds = (tiles + 255) / 256;
+      return (double)a.M * a.N / ((double)rounds * 256 * bm * 256);
+    };
+    if (g_gemm_force == 2 || (g_gemm_force == 0 && eff(256) >= eff(128))) return launch_dma_t<256, EPI>(a, s);   // force 3 -> BM 128
+    return launch_dma_t<128, EPI>(a, s);
+  }
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
@@ -209,6 +425,8 @@ hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+void gemm_force_kernel(int which) { g_gemm_force = which; }
 
 hipError_t launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;

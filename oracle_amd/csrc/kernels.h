@@ -17,6 +17,7 @@ struct GemmArgs {
   int Nvalid;                 // columns actually stored (<= N, or <= N/2 for SWIGLU)
 };
 hipError_t launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
+void gemm_force_kernel(int which);   // tools only: 0 auto, 1 = 128^2 register-staged, 2 / 3 = LDS-DMA kernel BM 256 / 128
 // decode-time skinny GEMM (M <= 16), same argument meaning; N multiple of 16 (32 for SWIGLU)
 hipError_t launch_gemv(const GemmArgs& a, int epi, hipStream_t s);
 // full argument set of the decode GEMV (fused rotary + KV-cache epilogue, sum-of-squares partials)

@@ -189,13 +189,15 @@ class Engine:
 
 
 # ---------------------------------------------------------------------- single-kernel hooks (tests, profiling)
-def test_gemm(x, w, bias=None, residual=None, epilogue='none', use_gemv=False):
+def test_gemm(x, w, bias=None, residual=None, epilogue='none', use_gemv=False, kernel=None):
+    """kernel: None (automatic), 'tile128' (register-staged 128^2), 'dma256' / 'dma128' (LDS-DMA, BM x 256 tiles)."""
     l = _lib.lib()
     m, k = x.shape
     n = w.shape[0]
     nout = n // 2 if epilogue == 'swiglu' else n
     out = torch.empty(m, nout, dtype=torch.float32 if epilogue == 'f32' else torch.bfloat16, device=x.device)
-    _lib.check(l.orc_test_gemm(_ptr(x), m, k, _ptr(w), n, _ptr(bias), _ptr(residual), EPI[epilogue], 1 if use_gemv else 0,
+    _lib.check(l.orc_test_gemm(_ptr(x), m, k, _ptr(w), n, _ptr(bias), _ptr(residual), EPI[epilogue],
+                               1 if use_gemv else {None: 0, 'tile128': 2, 'dma256': 3, 'dma128': 4}[kernel],
                                _ptr(out), _stream()), 'orc_test_gemm')
     return out
 

@@ -67,6 +67,27 @@ def test_gemm_shapes(K, N):
     assert rel_err(out2, ref[:8]) <= TOL
 
 
+@pytest.mark.parametrize('kernel', ['tile128', 'dma256', 'dma128'])
+@pytest.mark.parametrize('epi', ['none', 'quickgelu', 'gelu', 'residual', 'swiglu', 'f32'])
+def test_gemm_kernels_agree(kernel, epi):
+    """Every large-M GEMM kernel (register-staged 128^2; LDS-DMA BM x 256) against torch, ragged M and padded N."""
+    from oracle_amd import engine as E
+    M, K, N = 777, 1024, 640
+    x = _rand((M, K), 11)
+    w = _rand((N, K), 12, 0.03)
+    bias = _rand((N,), 13, 0.1) if epi not in ('swiglu', 'f32') else None
+    res = _rand((M, N), 14) if epi == 'residual' else None
+    y = F.linear(x, w, bias)
+    ref = {'none': y, 'quickgelu': y * torch.sigmoid(1.702 * y), 'gelu': F.gelu(y), 'residual': (res + y) if res is not None else y,
+           'swiglu': F.silu(y[:, :N // 2]) * y[:, N // 2:], 'f32': y.float()}[epi]
+    d = _dev()
+    out = E.test_gemm(x.to(d), w.to(d), None if bias is None else bias.to(d), None if res is None else res.to(d), epi, kernel=kernel)
+    torch.cuda.synchronize()
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) <= TOL
+    assert (out.float().cpu() == ref.float()).float().mean().item() > 0.6
+
+
 def test_norms():
     from oracle_amd import engine as E
     d = _dev()

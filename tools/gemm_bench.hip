@@ -1,0 +1,49 @@
+// Micro-benchmark of the large-M GEMM kernels on the prefill / ViT shapes (GPU box only).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include "../oracle_amd/csrc/common.h"
+#include "../oracle_amd/csrc/kernels.h"
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+__global__ void fill_kernel(uint16_t* p, size_t n, uint32_t seed) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    uint32_t h = (uint32_t)i * 2654435761u + seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    p[i] = (uint16_t)(((h & 1) << 15) | (0x3C00 + (h >> 8 & 0xFF)));
+  }
+}
+struct Shape { const char* name; int M, N, K, epi; };
+int main(int argc, char** argv) {
+  const int B = argc > 1 ? atoi(argv[1]) : 8;
+  const int Mp = B * 739, Mv = B * 3 * 577;
+  const Shape shapes[] = {
+      {"prefill qkv      ", Mp, 12288, 4096, EPI_NONE}, {"prefill o  +res  ", Mp, 4096, 4096, EPI_RESIDUAL},
+      {"prefill gu swiglu", Mp, 22016, 4096, EPI_SWIGLU}, {"prefill down+res ", Mp, 4096, 11008, EPI_RESIDUAL},
+      {"vit qkv          ", Mv, 3072, 1024, EPI_NONE}, {"vit o +res       ", Mv, 1024, 1024, EPI_RESIDUAL},
+      {"vit fc1 quickgelu", Mv, 4096, 1024, EPI_QUICKGELU}, {"vit fc2 +res     ", Mv, 1024, 4096, EPI_RESIDUAL},
+  };
+  bf16_t *X, *W, *R, *C, *bias;
+  CK(hipMalloc((void**)&X, (size_t)Mv * 11008 * 2)); CK(hipMalloc((void**)&W, (size_t)22016 * 4096 * 2 * 2));
+  CK(hipMalloc((void**)&R, (size_t)Mv * 4096 * 2)); CK(hipMalloc((void**)&C, (size_t)Mv * 12288 * 2)); CK(hipMalloc((void**)&bias, 65536));
+  hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, X, (size_t)Mv * 11008, 1u);
+  hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, W, (size_t)22016 * 4096 * 2, 2u);
+  hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, R, (size_t)Mv * 4096, 3u);
+  hipLaunchKernelGGL(fill_kernel, dim3(64), dim3(256), 0, 0, bias, 32768, 4u);
+  CK(hipDeviceSynchronize());
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (const Shape& sh : shapes)
+    for (int force = 1; force <= 3; ++force) {
+      GemmArgs a; a.X = X; a.ldx = sh.K; a.Wp = W; a.bias = bias; a.R = R; a.ldr = sh.N; a.C = C;
+      a.ldc = sh.epi == EPI_SWIGLU ? sh.N / 2 : sh.N; a.M = sh.M; a.N = sh.N; a.K = sh.K; a.Nvalid = a.ldc;
+      gemm_force_kernel(force);
+      for (int i = 0; i < 2; ++i) CK(launch_gemm(a, sh.epi, 0));
+      CK(hipEventRecord(e0, 0));
+      const int iters = 10;
+      for (int i = 0; i < iters; ++i) { a.Wp = W + (size_t)(i & 1) * 22016 * 4096; CK(launch_gemm(a, sh.epi, 0)); }
+      CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      const double us = ms * 1e3 / iters;
+      printf("%s M=%5d N=%5d K=%5d %s : %8.1f us  %7.1f TFLOP/s\n", sh.name, sh.M, sh.N, sh.K,
+             force == 1 ? "tile128" : (force == 2 ? "dma256 " : "dma128 "), us, 2.0 * sh.M * sh.N * sh.K / us * 1e-6);
+    }
+  return 0;
+}
