@@ -261,6 +261,7 @@ __global__ __launch_bounds__(512) void gemm_dma_kernel(GemmArgs a) {
       return *(const bf16x8*)(sx + row * 128 + (((kk * 4 + g) ^ (row & 7)) << 4));
     };
     bf16x8 xc[2] = {xread(0, 0), xread(0, 1)};
+    __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);       // the 8 W + 2 X reads above
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
       bf16x8 xn[2] = {xc[0], xc[1]};
@@ -271,6 +272,10 @@ __global__ __launch_bounds__(512) void gemm_dma_kernel(GemmArgs a) {
         for (int nt = 0; nt < 4; ++nt)
           acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk][nt], xc[kk], acc[nt][mt], 0, 0, 0);
       xc[0] = xn[0]; xc[1] = xn[1];
+      // issue order per m-tile: the next tile's two reads, then this tile's 8 MFMAs (otherwise the scheduler sinks the
+      // reads to just before their use and waits on them with the matrix pipe idle)
+      if (mt + 1 < MTW) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
     }
   }
 
