@@ -415,7 +415,8 @@ hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
       const long rounds = (tiles + 255) / 256;
       return (double)a.M * a.N / ((double)rounds * 256 * bm * 256);
     };
-    if (g_gemm_force == 2 || (g_gemm_force == 0 && eff(256) >= eff(128))) return launch_dma_t<256, EPI>(a, s);   // force 3 -> BM 128
+    // a 128-row tile runs at ~0.88x the per-tile rate of a 256-row one (tools/gemm_bench), so it must win that back in rounds
+    if (g_gemm_force == 2 || (g_gemm_force == 0 && eff(256) >= 0.88 * eff(128))) return launch_dma_t<256, EPI>(a, s);   // force 3 -> BM 128
     return launch_dma_t<128, EPI>(a, s);
   }
   static bool attr_set = false;
