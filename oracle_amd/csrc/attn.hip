@@ -249,16 +249,14 @@ __global__ __launch_bounds__(WAVES * 64) void decode_attn_kernel(DecodeAttnArgs 
   }
 }
 
-__global__ __launch_bounds__(128) void decode_attn_combine_kernel(DecodeAttnArgs a) {
+__global__ __launch_bounds__(128) void decode_attn_combine_kernel(DecodeAttnArgs a, int nsplit) {
   const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const float* pp = a.part + ((size_t)b * a.H + h) * DECODE_NSPLIT * 130;
   float mm = -INFINITY;
-#pragma unroll
-  for (int i = 0; i < DECODE_NSPLIT; ++i) mm = fmaxf(mm, pp[i * 130]);
+  for (int i = 0; i < nsplit; ++i) mm = fmaxf(mm, pp[i * 130]);
   const float m_use = (mm == -INFINITY) ? 0.f : mm;
   float ll = 0.f, av = 0.f;
-#pragma unroll
-  for (int i = 0; i < DECODE_NSPLIT; ++i) {
+  for (int i = 0; i < nsplit; ++i) {
     const float sc = rescale(pp[i * 130], m_use);
     ll += pp[i * 130 + 1] * sc;
     av += pp[i * 130 + 2 + tid] * sc;
@@ -301,8 +299,21 @@ hipError_t launch_decode_attention(const DecodeAttnArgs& a, hipStream_t s, int v
       default: hipLaunchKernelGGL((decode_attn_kernel<16, 1>), dim3(a.H, a.B, 1), dim3(1024), 0, s, a); break;
     }
   } else {
-    hipLaunchKernelGGL((decode_attn_kernel<4, 4>), dim3(a.H, a.B, DECODE_NSPLIT), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(decode_attn_combine_kernel, dim3(a.H, a.B), dim3(128), 0, s, a);
+    // few (row, head) pairs: split every key range so that about one workgroup per CU streams the cache
+    int nsplit = 256 / (a.B * a.H);
+    nsplit = nsplit < 2 ? 2 : (nsplit > DECODE_NSPLIT ? DECODE_NSPLIT : nsplit);
+    switch (variant) {
+#ifdef GEMV_ALL_VARIANTS
+      case 1: hipLaunchKernelGGL((decode_attn_kernel<4, 2>), dim3(a.H, a.B, nsplit), dim3(256), 0, s, a); break;
+      case 2: hipLaunchKernelGGL((decode_attn_kernel<8, 2>), dim3(a.H, a.B, nsplit), dim3(512), 0, s, a); break;
+      case 3: hipLaunchKernelGGL((decode_attn_kernel<8, 1>), dim3(a.H, a.B, nsplit), dim3(512), 0, s, a); break;
+      case 4: hipLaunchKernelGGL((decode_attn_kernel<16, 1>), dim3(a.H, a.B, nsplit), dim3(1024), 0, s, a); break;
+      case 5: hipLaunchKernelGGL((decode_attn_kernel<16, 2>), dim3(a.H, a.B, nsplit), dim3(1024), 0, s, a); break;
+      case 6: hipLaunchKernelGGL((decode_attn_kernel<4, 4>), dim3(a.H, a.B, nsplit), dim3(256), 0, s, a); break;
+#endif
+      default: hipLaunchKernelGGL((decode_attn_kernel<16, 1>), dim3(a.H, a.B, nsplit), dim3(1024), 0, s, a); break;
+    }
+    hipLaunchKernelGGL(decode_attn_combine_kernel, dim3(a.H, a.B), dim3(128), 0, s, a, nsplit);
   }
   return hipGetLastError();
 }

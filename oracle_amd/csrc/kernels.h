@@ -75,7 +75,7 @@ struct DecodeAttnArgs {
   int B, H;
   float scale;
 };
-#define DECODE_NSPLIT 4
+#define DECODE_NSPLIT 8   // capacity of the split-KV partial buffer; the launch picks 2..8 splits by batch
 hipError_t launch_decode_attention(const DecodeAttnArgs& a, hipStream_t s, int variant = 0);
 
 // ---- rotary + KV-cache write. qkv [rows][3*H*128]; row = b*T + t; q rotated in place.
