@@ -69,6 +69,17 @@ int orc_view_reduce(orc_engine* e, const void* x, int batch, int views, int64_t 
 /* encode_images_concat_pool (reference llava_arch.py:128-141): 2x2 max pool of the token grid. */
 int orc_pool2x2(orc_engine* e, const void* x, int n_images, int grid, int d, void* out, void* stream);
 
+/* process_images with image_aspect_ratio == 'pad' (reference LLaVA/llava/mm_utils.py:14-40) + the square-image part of
+ * CLIPImageProcessor.preprocess (third-party transformers; PIL bicubic resize, /255, mean/std) + the bf16 cast of
+ * scene_graph_prediction_model_oracle.py:65-67: n decoded RGB views of one size, uint8 HWC on the device ->
+ * (n, 3, out_size, out_size) bf16. bounds (out_size x 2 int32: first tap, tap count) and coeffs (out_size x ksize int32,
+ * 22-bit fixed point) are Pillow's resample tables for max(height, width) -> out_size; lut_bf16 is the (3, 256)
+ * normalisation table; fill_rgb_host the expand2square colour (3 ints, host); tmp >= n * max(height, width) *
+ * out_size * 3 bytes of device scratch. Integer arithmetic: bit-exact with PIL + numpy float32. No engine needed. */
+int orc_preprocess_images(const uint8_t* rgb_hwc, int n_images, int height, int width, int out_size,
+                          const int32_t* bounds, const int32_t* coeffs, int ksize, const void* lut_bf16,
+                          const int32_t* fill_rgb_host, void* tmp, void* out_pixel_values, void* stream);
+
 /* prepare_inputs_labels_for_multimodal, step 0 (reference llava_arch.py:245-359): gather the spliced
  * (rows, d_model) embedding matrix. codes[r] = kind<<28 | index; kind 0 = zero (padding) row,
  * 1 = embed_tokens[index], 2 = image_features[index], 3 = descriptors[index]. */

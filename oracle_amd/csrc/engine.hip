@@ -586,6 +586,16 @@ extern "C" int orc_pool2x2(orc_engine* e, const void* x, int n_images, int grid,
   return 0;
 }
 
+extern "C" int orc_preprocess_images(const uint8_t* rgb_hwc, int n_images, int height, int width, int out_size,
+                                     const int32_t* bounds, const int32_t* coeffs, int ksize, const void* lut_bf16,
+                                     const int32_t* fill_rgb_host, void* tmp, void* out, void* stream) {
+  if (!rgb_hwc || !bounds || !coeffs || !lut_bf16 || !fill_rgb_host || !tmp || !out) return fail("orc_preprocess_images", "null argument");
+  if (n_images < 1 || height < 1 || width < 1 || out_size < 1 || ksize < 1) return fail("orc_preprocess_images", "bad size");
+  HIPCHK(launch_preprocess(rgb_hwc, n_images, height, width, out_size, bounds, coeffs, ksize, (const bf16_t*)lut_bf16,
+                           fill_rgb_host[0], fill_rgb_host[1], fill_rgb_host[2], (uint8_t*)tmp, (bf16_t*)out, S(stream)));
+  return 0;
+}
+
 extern "C" int orc_splice(orc_engine* e, const int32_t* codes, int rows, const void* img, const void* desc, void* out,
                           void* stream) {
   if (!e || !e->finalized) return fail("orc_splice", "engine not finalized");

@@ -110,6 +110,10 @@ hipError_t launch_embed_tokens(const int* ids, const bf16_t* tok, bf16_t* out, i
 hipError_t launch_view_reduce(const bf16_t* x, bf16_t* out, int B, int V, int n, int mode, hipStream_t s);
 hipError_t launch_pool2x2(const bf16_t* x, bf16_t* out, int n_img, int grid, int d, hipStream_t s);
 
+// ---- image preprocessing: pad to square + Pillow-exact 8-bit bicubic resize + normalisation table (misc.hip)
+hipError_t launch_preprocess(const uint8_t* img, int n, int H, int W, int out, const int* bounds, const int* coef, int ksize,
+                             const bf16_t* lut, int fr, int fg, int fb, uint8_t* tmp, bf16_t* dst, hipStream_t s);
+
 // ---- greedy sampling state machine (device resident)
 struct SampleArgs {
   const float* logits; int vocab; int B;

@@ -201,6 +201,60 @@ __global__ void pool2x2_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict_
   }
 }
 
+// ------------------------------------------------------------------ image preprocessing
+// expand2square + Pillow's 8-bit bicubic resize (two passes, uint8 in between, 22-bit fixed-point coefficient tables
+// built on the host exactly as libImaging/Resample.c does) + /255 + mean/std normalisation (a 3 x 256 bf16 table).
+// Integer arithmetic throughout: bit-exact with the host path (PIL + numpy float32) by construction.
+// pass 1: rows of the padded square, horizontal taps.  grid (S, n), 128 threads over the output columns.
+__global__ __launch_bounds__(128) void resize_h_kernel(const uint8_t* __restrict__ img, int H, int W, int S, int out,
+                                                       const int* __restrict__ bounds, const int* __restrict__ coef, int ksize,
+                                                       int fr, int fg, int fb, uint8_t* __restrict__ tmp) {
+  const int y = blockIdx.x, im = blockIdx.y;
+  const int ox = (S - W) / 2, oy = (S - H) / 2;
+  const int sy = y - oy;
+  const bool row_in = sy >= 0 && sy < H;
+  const uint8_t* src = img + ((size_t)im * H + (row_in ? sy : 0)) * W * 3;
+  uint8_t* dst = tmp + ((size_t)im * S + y) * out * 3;
+  for (int xx = threadIdx.x; xx < out; xx += 128) {
+    const int x0 = bounds[2 * xx], cnt = bounds[2 * xx + 1];
+    int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21;
+    for (int t = 0; t < cnt; ++t) {
+      const int k = coef[xx * ksize + t];
+      const int sx = x0 + t - ox;
+      int r = fr, g = fg, b = fb;
+      if (row_in && sx >= 0 && sx < W) { r = src[sx * 3]; g = src[sx * 3 + 1]; b = src[sx * 3 + 2]; }
+      a0 += r * k; a1 += g * k; a2 += b * k;
+    }
+    a0 >>= 22; a1 >>= 22; a2 >>= 22;
+    dst[xx * 3] = (uint8_t)(a0 < 0 ? 0 : (a0 > 255 ? 255 : a0));
+    dst[xx * 3 + 1] = (uint8_t)(a1 < 0 ? 0 : (a1 > 255 ? 255 : a1));
+    dst[xx * 3 + 2] = (uint8_t)(a2 < 0 ? 0 : (a2 > 255 ? 255 : a2));
+  }
+}
+// pass 2: vertical taps over the pass-1 image, then the normalisation table; output (n, 3, out, out) bf16.
+__global__ __launch_bounds__(128) void resize_v_kernel(const uint8_t* __restrict__ tmp, int S, int out, const int* __restrict__ bounds,
+                                                       const int* __restrict__ coef, int ksize, const bf16_t* __restrict__ lut,
+                                                       bf16_t* __restrict__ dst) {
+  const int yy = blockIdx.x, im = blockIdx.y;
+  const int y0 = bounds[2 * yy], cnt = bounds[2 * yy + 1];
+  const uint8_t* src = tmp + (size_t)im * S * out * 3;
+  for (int xx = threadIdx.x; xx < out; xx += 128) {
+    int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21;
+    for (int t = 0; t < cnt; ++t) {
+      const int k = coef[yy * ksize + t];
+      const uint8_t* p = src + ((size_t)(y0 + t) * out + xx) * 3;
+      a0 += p[0] * k; a1 += p[1] * k; a2 += p[2] * k;
+    }
+    a0 >>= 22; a1 >>= 22; a2 >>= 22;
+    a0 = a0 < 0 ? 0 : (a0 > 255 ? 255 : a0);
+    a1 = a1 < 0 ? 0 : (a1 > 255 ? 255 : a1);
+    a2 = a2 < 0 ? 0 : (a2 > 255 ? 255 : a2);
+    const size_t plane = (size_t)out * out;
+    bf16_t* o = dst + (size_t)im * 3 * plane + (size_t)yy * out + xx;
+    o[0] = lut[a0]; o[plane] = lut[256 + a1]; o[2 * plane] = lut[512 + a2];
+  }
+}
+
 // ------------------------------------------------------------------ greedy sampling
 // One workgroup per batch row: argmax over the vocabulary (lowest index on exact ties, as torch.argmax),
 // then the greedy-search bookkeeping (transformers GenerationMixin greedy search):
@@ -310,6 +364,15 @@ hipError_t launch_view_reduce(const bf16_t* x, bf16_t* out, int B, int V, int n,
 }
 hipError_t launch_pool2x2(const bf16_t* x, bf16_t* out, int n_img, int grid, int d, hipStream_t s) {
   hipLaunchKernelGGL(pool2x2_kernel, dim3(grid_for((size_t)n_img * (grid / 2) * (grid / 2) * d)), dim3(256), 0, s, x, out, n_img, grid, d);
+  return hipGetLastError();
+}
+hipError_t launch_preprocess(const uint8_t* img, int n, int H, int W, int out, const int* bounds, const int* coef, int ksize,
+                             const bf16_t* lut, int fr, int fg, int fb, uint8_t* tmp, bf16_t* dst, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  if (H <= 0 || W <= 0 || out <= 0 || ksize <= 0) return hipErrorInvalidValue;
+  const int S = H > W ? H : W;
+  hipLaunchKernelGGL(resize_h_kernel, dim3(S, n), dim3(128), 0, s, img, H, W, S, out, bounds, coef, ksize, fr, fg, fb, tmp);
+  hipLaunchKernelGGL(resize_v_kernel, dim3(out, n), dim3(128), 0, s, tmp, S, out, bounds, coef, ksize, lut, dst);
   return hipGetLastError();
 }
 hipError_t launch_argmax_sample(const SampleArgs& a, hipStream_t s) {

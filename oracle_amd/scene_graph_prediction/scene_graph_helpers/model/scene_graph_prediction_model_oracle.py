@@ -10,6 +10,7 @@ import itertools
 import re
 from collections import defaultdict
 
+import numpy as np
 import torch
 from PIL import Image
 
@@ -28,7 +29,8 @@ MEMORY_CHAR_LIMIT = 5000
 
 class OracleWrapper:
     def __init__(self, config, num_class, num_rel, weights_obj, weights_rel, relationNames, model_path,
-                 model_base='liuhaotian/llava-v1.5-7b', load_8bit=False, load_4bit=False, mv_desc=False, **engine_kw):
+                 model_base='liuhaotian/llava-v1.5-7b', load_8bit=False, load_4bit=False, mv_desc=False,
+                 device_preprocess=True, **engine_kw):
         self.config = config
         self.mconfig = config['MODEL']
         self.n_object_types = 6
@@ -43,6 +45,7 @@ class OracleWrapper:
         self.model.config.mv_type = self.mconfig['mv_type']
         self.model.config.tokenizer_padding_side = 'left'
         self.mv_desc = mv_desc
+        self.device_preprocess, self._preproc = device_preprocess, None
         self.temporal_online_prediction = config.get('temporality') == 'PRED'
         if self.temporal_online_prediction:
             print('Preparing temporality PRED')
@@ -92,6 +95,15 @@ class OracleWrapper:
 
     def load_views(self, elem):
         views = [Image.open(elem['image_paths'][cam - 1]).convert('RGB') for cam in self.config['CAMERAS']]
+        if (self.device_preprocess and torch.device(self.model.device).type == 'cuda' and len({v.size for v in views}) == 1
+                and getattr(self.model.config, 'image_aspect_ratio', None) == 'pad'):
+            # pad + PIL-exact bicubic resize + normalisation on the device (oracle_amd/preprocess.py); same bits as
+            # process_images() followed by the bf16 cast, same shapes ((1,V,3,S,S) for V > 1, (1,3,S,S) for one view)
+            if self._preproc is None:
+                from ....preprocess import DevicePreprocessor
+                self._preproc = DevicePreprocessor(self.image_processor, self.model.device)
+            t = self._preproc([np.asarray(v) for v in views])
+            return t if len(views) == 1 else t[None]
         t = process_images(views, self.image_processor, self.model.config)
         if type(t) is list:
             return [x.to(self.model.device, dtype=torch.bfloat16) for x in t]
