@@ -81,6 +81,20 @@ def test_view_fusion_variants(tiny):
     assert rel_err(gp, ref) <= TOL
 
 
+def test_visual_descriptor_embeddings(tiny):
+    """embed_visual_prompts.py:46-48: mm_projector(CLIP pooler_output) per crop, against the CPU oracle."""
+    from oracle import cpu_ref as cr
+    from oracle_amd.dims import TINY
+    from oracle_amd.synth import synth_images
+    from oracle_amd.synthetic_or_generation.embed_visual_prompts import process_and_extract_features
+    st, eng, model = tiny
+    crops = synth_images(5, 1, TINY, seed=31)
+    got = process_and_extract_features(crops[None], model)
+    ref = cr.mm_projector(st, cr.vision_tower_global(st, TINY, crops))
+    assert got.shape == (5, TINY.d_model)
+    assert rel_err(got, ref) <= TOL
+
+
 def test_splice_rows_are_exact_copies(tiny):
     from oracle import cpu_ref as cr
     from oracle_amd.dims import TINY
