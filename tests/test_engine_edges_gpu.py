@@ -1,0 +1,97 @@
+"""GPU edge cases of the hot path through the mirrored API: the largest batch the engine takes (16 rows, ragged left
+padding, rows finishing at different steps) against the CPU oracle and against the same rows run alone (batch
+invariance); a text-only prompt; capacity / argument errors raised the way the mirror documents them."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def chain16():
+    from oracle_amd.dims import TINY
+    from oracle_amd.engine import Engine
+    from oracle_amd.llava.model.language_model.llava_llama import LlavaConfig, LlavaLlamaForCausalLM
+    from oracle_amd.synth import install_chain, synth_state
+    st = install_chain(synth_state(TINY, seed=0), TINY)
+    eng = Engine(TINY, max_batch=16, max_seq=700, max_images=48, max_new_tokens=48)
+    eng.load_state(st)
+    model = LlavaLlamaForCausalLM(LlavaConfig(TINY, tokenizer_padding_side='left'), eng)
+    yield st, eng, model
+    eng.close()
+
+
+def _prompts(n):
+    from oracle_amd.synth import CHAIN_BASE, CHAIN_LEN
+    e = CHAIN_BASE + CHAIN_LEN
+    g = torch.Generator().manual_seed(3)
+    rows = []
+    for i in range(n):
+        pre = torch.randint(3, 1000, (1 + i % 5,), generator=g).tolist()
+        post = torch.randint(3, 1000, (i % 4,), generator=g).tolist()
+        rows.append([1] + pre + [-200] + post + [e - 3 - 2 * i])          # row i emits 3 + 2i tokens, then EOS
+    L = max(len(r) for r in rows)
+    return torch.tensor([[0] * (L - len(r)) + r for r in rows])
+
+
+def test_batch_of_16_ragged_rows_matches_oracle_and_single_rows(chain16):
+    from oracle import cpu_ref as cr
+    from oracle_amd.dims import TINY
+    from oracle_amd.synth import synth_images
+    st, eng, model = chain16
+    ids = _prompts(16)
+    imgs = synth_images(16, 3, TINY, seed=77)
+    out = model.generate(ids.cuda(), images=imgs.cuda(), do_sample=False, use_cache=True, max_new_tokens=40).cpu()
+    ref = cr.greedy_generate(st, TINY, ids, imgs, max_new_tokens=40)
+    assert torch.equal(out, ref)
+    new = out[:, ids.shape[1]:]
+    for i in (0, 7, 15):                                                    # EOS after 3 + 2i tokens, pad afterwards
+        n = 3 + 2 * i
+        assert new[i, n].item() == 2 and (n + 1 >= new.shape[1] or bool((new[i, n + 1:] == 0).all()))
+    # the same rows alone (no padding, batch 1): identical tokens up to their EOS
+    for i in (0, 9, 15):
+        row = ids[i][ids[i] != 0][None]
+        one = model.generate(row.cuda(), images=imgs[i:i + 1].cuda(), max_new_tokens=40).cpu()
+        n = 3 + 2 * i + 1
+        assert torch.equal(one[0, row.shape[1]:row.shape[1] + n], new[i, :n])
+
+
+def test_text_only_prompt_and_batch_one(chain16):
+    from oracle import cpu_ref as cr
+    from oracle_amd.dims import TINY
+    from oracle_amd.synth import CHAIN_BASE, CHAIN_LEN
+    st, eng, model = chain16
+    ids = torch.tensor([[1, 17, 18, 19, CHAIN_BASE + CHAIN_LEN - 6]])
+    out = model.generate(ids.cuda(), images=None, max_new_tokens=12).cpu()
+    emb = st['model.embed_tokens.weight'][ids]
+    logits, _ = cr.llama_forward(st, TINY, emb, torch.ones_like(ids, dtype=torch.bool), torch.arange(ids.shape[1])[None])
+    assert out[0, ids.shape[1]].item() == int(logits.argmax(-1))
+    assert out[0, -1].item() == 2 and out.shape[1] == ids.shape[1] + 7
+
+
+def test_capacity_and_argument_errors(chain16):
+    from oracle_amd import _lib
+    from oracle_amd.dims import TINY
+    from oracle_amd.synth import synth_images
+    st, eng, model = chain16
+    ids = _prompts(2)
+    imgs = synth_images(2, 3, TINY, seed=5).cuda()
+    with pytest.raises(ValueError, match='max_new_tokens'):
+        model.generate(ids.cuda(), images=imgs, max_new_tokens=49)
+    with pytest.raises(ValueError, match='KV capacity'):
+        model.generate(torch.cat([ids, ids.new_full((2, 120), 5)], 1).cuda(), images=imgs, max_new_tokens=40)
+    with pytest.raises(NotImplementedError):
+        model.generate(ids.cuda(), images=imgs, do_sample=True)
+    right_padded = torch.tensor([[1, 5, -200, 6, 0, 0], [1, 5, -200, 6, 7, 8]])
+    # the splice re-pads to the configured side (llava_arch.py:338-359); the native LLaMA path refuses right padding
+    model.config.tokenizer_padding_side = 'right'
+    try:
+        with pytest.raises(NotImplementedError, match='left-padded'):
+            model(input_ids=right_padded.cuda(), attention_mask=(right_padded != 0).cuda(), images=imgs)
+    finally:
+        model.config.tokenizer_padding_side = 'left'
+    model(input_ids=right_padded.cuda(), attention_mask=(right_padded != 0).cuda(), images=imgs)         # re-padded left: fine
+    with pytest.raises(_lib.OracleHipError):
+        eng.pool_views(torch.zeros(5 * 3, 576, 1024, dtype=torch.bfloat16, device='cuda'), [5, 5, 5])   # 5 views > pooler's 2304 positions
+    with pytest.raises(ValueError):
+        eng.vision_encode(torch.zeros(1, 3, 336, 336, device='cuda'))                                    # fp32 images are refused
