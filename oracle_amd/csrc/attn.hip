@@ -3,8 +3,8 @@
 //   LLaMA prefill (32 heads x 128, causal + left-pad mask).
 // and a split-KV streaming kernel for decode (one query per row, HBM-bound on the KV cache).
 //
-// Prefill kernel: one workgroup = 4 waves = 64 query rows, each wave 16 rows; K/V tiles of 32 keys staged
-// in LDS (XOR-swizzled so both the ds_read_b128 K reads and the ds_read_b64_tr_b16 V reads are
+// Prefill kernel: one workgroup = 4 waves = 128 query rows, each wave 2 x 16 rows; K/V tiles of 64 keys staged
+// in LDS by LDS-DMA (XOR-swizzled so both the ds_read_b128 K reads and the ds_read_b64_tr_b16 V reads are
 // conflict-free). Orientation is chosen so that no data crosses lanes between the two products:
 //   S^T = K . Q^T   (A = K tile from LDS, B = Q^T fragment held in registers)  -> lane holds, for its
 //                    query column q = lane&15, keys 4g..4g+3 of each 16-key block (g = lane>>4)
@@ -23,115 +23,173 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 template <int HD> __device__ __forceinline__ int fK(int key) { return HD == 128 ? (key & 15) : ((key >> 1) & 7); }
 template <int HD> __device__ __forceinline__ int fV(int key) { return HD == 128 ? (key & 7) : ((key >> 1) & 3); }
 
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+
+// One workgroup = 4 waves = 128 query rows (each wave two 16-row blocks, so every K / V fragment read from LDS feeds two
+// MFMAs); K/V tiles of 64 keys arrive by LDS-DMA (global_load_lds, 16 B per lane) into a 2-deep ring:
+//     wait my DMA of stage s -> barrier -> issue the DMA of tile t+1 -> compute on tile t
+// The XOR swizzles of the K image (ds_read_b128) and of the V image (ds_read_b64_tr_b16) permute 16-B chunks inside a
+// row, so they are applied to the per-lane SOURCE address (LDS-DMA destinations are lane-linear).
 template <int HD>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
-  constexpr int KB = 32;
+  constexpr int KB = 64;
   constexpr int ROWB = HD * 2;
-  constexpr int CH = HD / 8;   // 16-byte chunks per key row
-  __shared__ __attribute__((aligned(16))) char sK[KB * ROWB];
-  __shared__ __attribute__((aligned(16))) char sV[KB * ROWB];
+  constexpr int CH = HD / 8;                 // 16-byte chunks per key row
+  constexpr int TILE = KB * ROWB;            // bytes of one K (or V) tile
+  constexpr int RND = KB * CH / 256;         // DMA instructions per wave per operand per tile
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE];   // [stage][K | V]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int g = lane >> 4, r16 = lane & 15;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int qblk = blockIdx.x * 64;
+  const int qblk = blockIdx.x * 128;
   const int kb_ = a.kbeg ? a.kbeg[b] : 0;
   const int ke_ = a.kend ? a.kend[b] : a.Sk;
 
-  const int qrow = qblk + w * 16 + r16;
-  const int qrow_c = qrow < a.Sq ? qrow : a.Sq - 1;
-  const bf16_t* qp = a.Q + (size_t)b * a.q_bs + (size_t)h * a.q_hs + (size_t)qrow_c * a.q_ts;
-  bf16x8 qf[HD / 32];
+  bf16x8 qf[2][HD / 32];
+  int qi[2];
 #pragma unroll
-  for (int kk = 0; kk < HD / 32; ++kk) qf[kk] = *(const bf16x8*)(qp + kk * 32 + g * 8);
-
-  int q_hi = qblk + 63;
+  for (int qb = 0; qb < 2; ++qb) {
+    const int qrow = qblk + w * 32 + qb * 16 + r16;
+    const int qrow_c = qrow < a.Sq ? qrow : a.Sq - 1;
+    const bf16_t* qp = a.Q + (size_t)b * a.q_bs + (size_t)h * a.q_hs + (size_t)qrow_c * a.q_ts;
+#pragma unroll
+    for (int kk = 0; kk < HD / 32; ++kk) qf[qb][kk] = *(const bf16x8*)(qp + kk * 32 + g * 8);
+    qi[qb] = qrow + a.q_off;
+  }
+  int q_hi = qblk + 127;
   if (q_hi > a.Sq - 1) q_hi = a.Sq - 1;
   int k_hi = ke_;
   if (a.causal && q_hi + a.q_off + 1 < k_hi) k_hi = q_hi + a.q_off + 1;
-  const int qi = qrow + a.q_off;
+  const int qw_hi = qblk + w * 32 + 31 + a.q_off;            // last key this wave can see under the causal mask
 
-  f32x4 o[HD / 16];
+  f32x4 o[2][HD / 16];
 #pragma unroll
-  for (int i = 0; i < HD / 16; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m = -INFINITY, l = 0.f;
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int i = 0; i < HD / 16; ++i) o[qb][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
 
   const bf16_t* kbase = a.K + (size_t)b * a.k_bs + (size_t)h * a.k_hs;
   const bf16_t* vbase = a.V + (size_t)b * a.v_bs + (size_t)h * a.v_hs;
-
-  for (int k0 = (kb_ / KB) * KB; k0 < k_hi; k0 += KB) {
-    __syncthreads();
-    for (int c = tid; c < KB * CH; c += 256) {
-      const int key = c / CH, ch = c % CH;
+  auto dma = [&](int k0, int stage) {
+    char* sk = smem + stage * 2 * TILE;
+    char* sv = sk + TILE;
+#pragma unroll
+    for (int r = 0; r < RND; ++r) {
+      const int p = r * 256 + w * 64 + lane;                 // linear 16-B slot of the LDS image
+      const int key = p / CH, cp = p % CH;
       int gk = k0 + key;
       gk = gk < a.Sk ? gk : a.Sk - 1;
-      const u32x4 kv = *(const u32x4*)(kbase + (size_t)gk * a.k_ts + ch * 8);
-      const u32x4 vv = *(const u32x4*)(vbase + (size_t)gk * a.v_ts + ch * 8);
-      *(u32x4*)(sK + key * ROWB + ((ch ^ fK<HD>(key)) << 4)) = kv;
-      *(u32x4*)(sV + key * ROWB + ((((ch >> 1) ^ fV<HD>(key)) << 5) | ((ch & 1) << 4))) = vv;
+      const int ck = cp ^ fK<HD>(key);
+      const int cv = (((cp >> 1) ^ fV<HD>(key)) << 1) | (cp & 1);
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(kbase + (size_t)gk * a.k_ts + ck * 8), (lds_void_t*)(sk + (r * 256 + w * 64) * 16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(vbase + (size_t)gk * a.v_ts + cv * 8), (lds_void_t*)(sv + (r * 256 + w * 64) * 16), 16, 0, 0);
     }
-    __syncthreads();
+  };
 
-    float s[8];
+  const int k_first = (kb_ / KB) * KB;
+  if (k_first < k_hi) dma(k_first, 0);
+  int stage = 0;
+  for (int k0 = k_first; k0 < k_hi; k0 += KB, stage ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (k0 + KB < k_hi) dma(k0 + KB, stage ^ 1);
+    if (a.causal && k0 > qw_hi) continue;                    // every key of this tile is in this wave's future
+    const char* sK = smem + stage * 2 * TILE;
+    const char* sV = sK + TILE;
+
+    // scores: bf16 rounding after QK^T and again after the scale (the reference's two eager ops). The softmax below is
+    // VALU-bound (about 10 vector ops per score against 1/8 of an MFMA), so a tile that no mask touches -- every tile but
+    // the padding edge and the causal diagonal -- skips the per-element key tests.
+    const bool need_mask = k0 < kb_ || k0 + KB > ke_ || (a.causal && k0 + KB - 1 > qblk + w * 32 + a.q_off);
+    float s[2][16];
 #pragma unroll
-    for (int kb2 = 0; kb2 < 2; ++kb2) {
-      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int key_l = kb2 * 16 + r16;
+    for (int kb4 = 0; kb4 < 4; ++kb4) {
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      const int key_l = kb4 * 16 + r16;
 #pragma unroll
       for (int kk = 0; kk < HD / 32; ++kk) {
         const int c = kk * 4 + g;
         const bf16x8 kf = *(const bf16x8*)(sK + key_l * ROWB + ((c ^ fK<HD>(key_l)) << 4));
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], acc, 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][kk], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][kk], acc[1], 0, 0, 0);
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key_abs = k0 + kb2 * 16 + 4 * g + r;
-        const bool ok = key_abs >= kb_ && key_abs < ke_ && (!a.causal || key_abs <= qi);
-        const float sc = rbf(rbf(acc[r]) * a.scale);
-        s[kb2 * 4 + r] = ok ? sc : -INFINITY;
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          float x0, x1;
+          rbf2(acc[qb][r], acc[qb][r + 1], x0, x1);
+          rbf2(x0 * a.scale, x1 * a.scale, x0, x1);
+          s[qb][kb4 * 4 + r] = x0;
+          s[qb][kb4 * 4 + r + 1] = x1;
+        }
+    }
+    if (need_mask) {
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int key_abs = k0 + (j >> 2) * 16 + 4 * g + (j & 3);
+          const bool ok = key_abs >= kb_ && key_abs < ke_ && (!a.causal || key_abs <= qi[qb]);
+          s[qb][j] = ok ? s[qb][j] : -INFINITY;
+        }
+    }
+    bf16x8 pf[2][2];
+    float alpha[2];
+    constexpr float LOG2E = 1.4426950408889634f;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      float tm = s[qb][0];
+#pragma unroll
+      for (int j = 1; j < 16; ++j) tm = fmaxf(tm, s[qb][j]);
+      tm = fmaxf(tm, __shfl_xor(tm, 16, 64));
+      tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+      const float m_new = fmaxf(m[qb], tm);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      const float mb = -m_use * LOG2E;
+      alpha[qb] = __builtin_amdgcn_exp2f(fmaf(m[qb], LOG2E, mb));     // exp2(-inf) = 0 covers the first tile
+      float rs = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[qb][j], LOG2E, mb));   // masked keys: exp2(-inf) = 0
+        rs += p;
+        pf[qb][j >> 3][j & 7] = (__bf16)p;
       }
+      rs += __shfl_xor(rs, 16, 64);
+      rs += __shfl_xor(rs, 32, 64);
+      l[qb] = l[qb] * alpha[qb] + rs;
+      m[qb] = m_new;
     }
-    float tm = s[0];
-#pragma unroll
-    for (int j = 1; j < 8; ++j) tm = fmaxf(tm, s[j]);
-    tm = fmaxf(tm, __shfl_xor(tm, 16, 64));
-    tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
-    const float m_new = fmaxf(m, tm);
-    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = (m == -INFINITY) ? 0.f : __expf(m - m_use);
-    float p[8];
-    float rs = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      p[j] = (s[j] == -INFINITY) ? 0.f : __expf(s[j] - m_use);
-      rs += p[j];
-    }
-    rs += __shfl_xor(rs, 16, 64);
-    rs += __shfl_xor(rs, 32, 64);
-    l = l * alpha + rs;
-    m = m_new;
-    bf16x8 pf;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) pf[j] = (__bf16)p[j];
 #pragma unroll
     for (int dt = 0; dt < HD / 16; ++dt) {
-      o[dt] *= alpha;
-      const int key_a = 4 * g + (r16 >> 2);
-      const int within = 8 * (r16 & 3);
-      const char* p0 = sV + key_a * ROWB + ((dt ^ fV<HD>(key_a)) << 5) + within;
-      const char* p1 = sV + (key_a + 16) * ROWB + ((dt ^ fV<HD>(key_a + 16)) << 5) + within;
-      const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p0);
-      const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p1);
-      const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+      o[0][dt] *= alpha[0];
+      o[1][dt] *= alpha[1];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int key_a = hh * 32 + 4 * g + (r16 >> 2);
+        const int within = 8 * (r16 & 3);
+        const char* p0 = sV + key_a * ROWB + ((dt ^ fV<HD>(key_a)) << 5) + within;
+        const char* p1 = sV + (key_a + 16) * ROWB + ((dt ^ fV<HD>(key_a + 16)) << 5) + within;
+        const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p0);
+        const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p1);
+        const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+        o[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[0][hh], o[0][dt], 0, 0, 0);
+        o[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1][hh], o[1][dt], 0, 0, 0);
+      }
     }
   }
 
-  if (qrow < a.Sq) {
-    const float inv = l > 0.f ? 1.0f / l : 0.f;
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int qrow = qblk + w * 32 + qb * 16 + r16;
+    if (qrow >= a.Sq) continue;
+    const float inv = l[qb] > 0.f ? 1.0f / l[qb] : 0.f;
     bf16_t* op = a.O + (size_t)b * a.o_bs + (size_t)h * a.o_hs + (size_t)qrow * a.o_ts;
 #pragma unroll
     for (int dt = 0; dt < HD / 16; ++dt) {
-      u32x2 st = {pack2(o[dt][0] * inv, o[dt][1] * inv), pack2(o[dt][2] * inv, o[dt][3] * inv)};
+      u32x2 st = {pack2(o[qb][dt][0] * inv, o[qb][dt][1] * inv), pack2(o[qb][dt][2] * inv, o[qb][dt][3] * inv)};
       *(u32x2*)(op + dt * 16 + 4 * g) = st;
     }
   }
@@ -268,7 +326,7 @@ __global__ __launch_bounds__(128) void decode_attn_combine_kernel(DecodeAttnArgs
 
 hipError_t launch_attention(const AttnArgs& a, int head_dim, hipStream_t s) {
   if (a.B <= 0 || a.Sq <= 0 || a.Sk <= 0) return hipSuccess;
-  dim3 grid((a.Sq + 63) / 64, a.H, a.B);
+  dim3 grid((a.Sq + 127) / 128, a.H, a.B);
   if (head_dim == 128)
     hipLaunchKernelGGL(attn_kernel<128>, grid, dim3(256), 0, s, a);
   else if (head_dim == 64)

@@ -22,6 +22,16 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
 // tensors) materialises a tensor is one such rounding.
 __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
 
+// two values through bf16 with one v_cvt_pk_bf16_f32
+__device__ __forceinline__ void rbf2(float a, float b, float& ra, float& rb) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+  const bf16x2_t h = __builtin_convertvector((f32x2_t){a, b}, bf16x2_t);
+  const uint32_t u = __builtin_bit_cast(uint32_t, h);
+  ra = __uint_as_float(u << 16);
+  rb = __uint_as_float(u & 0xFFFF0000u);
+}
+
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
   return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }
