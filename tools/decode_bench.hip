@@ -149,6 +149,33 @@ int main(int argc, char** argv) {
       else printf("%s W%-2d U%d    : %7.2f us  %7.1f GB/s\n", sh.name, 1 << (vi / 3), variant == 15 ? 1 : 2 << (vi % 3), us, wbytes / us * 1e-3);
     }
   }
+  // ---- does a prefetch of the head of W (Infinity Cache warm-up during the small norm launch) shorten the GEMV?
+  if (getenv("PREFETCH_EXP")) {
+    for (const Shape& sh : {shapes[0], shapes[2]}) {
+      const size_t wbytes = (size_t)sh.N * sh.K * 2;
+      GemvArgs a = {};
+      a.X = X; a.ldx = sh.K; a.R = R; a.ldr = sh.N; a.C = Y;
+      a.ldc = sh.epi == EPI_SWIGLU ? sh.N / 2 : d;
+      a.M = M; a.N = sh.N; a.K = sh.K; a.Nvalid = sh.epi == EPI_SWIGLU ? sh.N / 2 : sh.N;
+      a.H = H; a.kbeg = ints + 16; a.cur_len = ints; a.cos_tab = cosb; a.sin_tab = sinb;
+      a.maxpos = 4096; a.Kc = Kc; a.Vc = Vc; a.c_bs = (long)H * Tmax * 128; a.c_hs = (long)Tmax * 128;
+      for (size_t mb : {0, 8, 16, 32, 64}) {
+        const size_t pf = mb << 20;
+        float both = time_it([&](int i) {
+          const size_t off = (((size_t)i * wbytes) % (pool_bytes - wbytes)) & ~(size_t)1023;
+          a.Wp = (const bf16_t*)((char*)pool + off);
+          if (pf) hipLaunchKernelGGL(read_kernel, dim3(1024), dim3(512), 0, s, (const u32x4*)((char*)pool + off), pf / 16, (uint32_t*)Y + 64);
+          CK(launch_gemv_ex(a, sh.epi, 0, s));
+        });
+        float rd = 0.f;
+        if (pf) rd = time_it([&](int i) {
+          const size_t off = (((size_t)i * wbytes) % (pool_bytes - wbytes)) & ~(size_t)1023;
+          hipLaunchKernelGGL(read_kernel, dim3(1024), dim3(512), 0, s, (const u32x4*)((char*)pool + off), pf / 16, (uint32_t*)Y + 64);
+        });
+        printf("%s prefetch %2zu MB : read+gemv %7.2f us, read alone %7.2f us -> gemv part %7.2f us\n", sh.name, mb, both, rd, both - rd);
+      }
+    }
+  }
   // ---- the two small norm launches
   {
     float us = time_it([&](int i) { CK(launch_rmsnorm_part(X, d, ssq, 256, lnw, R, d, M, d, 1e-5f, s)); });
