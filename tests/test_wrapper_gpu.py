@@ -21,3 +21,36 @@ def test_cli_end_to_end_device_vs_host_preprocessing(tmp_path, monkeypatch):
     monkeypatch.setattr(wmod.OracleWrapper, '__init__', host_init)
     host = cli.main(argv)
     assert len(dev) == 10 and dev == host
+
+
+def test_adaptability_cli_end_to_end(tmp_path, monkeypatch, capsys):
+    """adaptability_4dor_eval -> AdaptabilityOracleWrapper -> generate() on the native engine, visual-descriptor variant:
+    8 / 7 descriptor embeddings spliced per prompt; the report must come out and repeat exactly on a second run."""
+    import json
+
+    import numpy as np
+    import torch
+    from PIL import Image
+    from oracle_amd.scene_graph_prediction import adaptability_4dor_eval as cli
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(0)
+    d_model = 512                                    # synthetic:tiny
+    crops = tmp_path / 'synthetic_or_generation' / 'original_crops'
+    crops.mkdir(parents=True)
+    g = torch.Generator().manual_seed(1)
+    for n in ('anesthesia equipment', 'cementing', 'cutting', 'drilling', 'hammering', 'sawing', 'suturing'):
+        torch.save(torch.randn(d_model, generator=g) * 0.02, crops / f'{n}_cam2.pt')
+    for label in ('drilling', 'kuka'):
+        for sub in ('positives', 'negatives', 'visual_features'):
+            (tmp_path / 'adaptability_4dor' / label / sub).mkdir(parents=True)
+        base = tmp_path / 'adaptability_4dor' / label
+        for sub in ('positives', 'negatives'):
+            Image.fromarray(rng.integers(0, 256, size=(48, 64, 3), dtype=np.uint8)).save(base / sub / 'c0.jpg')
+        (base / 'positives' / 'c0.json').write_text(json.dumps({
+            'vis_img_name': 'v0.jpg', 'test_condition': f'<head surgeon>,<patient>,<{label}>',
+            'textual_attributes': {'color': 'red', 'size': 'large', 'shape': 'round', 'texture': 'metal', 'object_type': 'robot'}}))
+        torch.save(torch.randn(d_model, generator=g) * 0.02, base / 'visual_features' / 'v0_crop.pt')
+    argv = ['--config', 'oracle_mv_learned_symbolic_visual.json', '--model_path', 'synthetic:tiny:chain']
+    first = cli.main(argv)
+    second = cli.main(argv)
+    assert first == second and 'drilling' in first and 'kuka' in first
