@@ -22,6 +22,114 @@ namespace {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// ---- epilogues. `red` = this unit's partial D tiles [WAVES][NT][64 lanes][4]; a lane holds column b = lane & 15 (batch
+// row) and rows n = 16 * tile + 4 * (lane >> 4) + r of a D tile.
+// Paired epilogues (one wave): tile 0 and tile 1 of the unit are partners (gate / up, or rotary halves).
+template <int NT, int EPI, int WAVES>
+__device__ __forceinline__ void epilogue_pair(const GemvArgs& a, const float (*red)[NT][64][4], int pair, int lane) {
+  static_assert(NT == 2, "paired tiles");
+  const int g = lane >> 4, b = lane & 15;
+  f32x4 t0 = f32x4{0.f, 0.f, 0.f, 0.f}, t1 = t0;
+#pragma unroll
+  for (int i = 0; i < WAVES; ++i) {
+    t0 += *(const f32x4*)&red[i][0][lane][0];
+    t1 += *(const f32x4*)&red[i][1][lane][0];
+  }
+  if (b >= a.M) return;
+  if constexpr (EPI == EPI_SWIGLU) {
+    const int n = pair * 16 + 4 * g;
+    if (n >= a.Nvalid) return;
+    float o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float gg = rbf(t0[r]);
+      const float s = rbf(gg * sigmoidf_(gg));
+      o[r] = s * rbf(t1[r]);
+    }
+    u32x2 st = {pack2(o[0], o[1]), pack2(o[2], o[3])};
+    *(u32x2*)((bf16_t*)a.C + (size_t)b * a.ldc + n) = st;
+  } else {
+    // rows were packed so that tile 0 holds head dims [d0, d0+16) and tile 1 their rotary partners [d0+64, ...)
+    const int hs = pair >> 2, d = (pair & 3) * 16 + 4 * g;
+    const int sec = hs / a.H, h = hs % a.H;
+    const int len = *a.cur_len;
+    const int pos_raw = len - 1 - a.kbeg[b];
+    const int pos = pos_raw < 0 ? 0 : (pos_raw >= a.maxpos ? a.maxpos - 1 : pos_raw);
+    const int slot = len - 1;
+    float lo[4], hi[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { lo[r] = rbf(t0[r]); hi[r] = rbf(t1[r]); }
+    if (sec < 2) {
+      const u32x2 cv = *(const u32x2*)(a.cos_tab + (size_t)pos * 64 + d);
+      const u32x2 sv = *(const u32x2*)(a.sin_tab + (size_t)pos * 64 + d);
+      const float c[4] = {lo_bf(cv[0]), hi_bf(cv[0]), lo_bf(cv[1]), hi_bf(cv[1])};
+      const float s[4] = {lo_bf(sv[0]), hi_bf(sv[0]), lo_bf(sv[1]), hi_bf(sv[1])};
+      float ol[4], oh[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        ol[r] = rbf(lo[r] * c[r]) + rbf(-hi[r] * s[r]);
+        oh[r] = rbf(hi[r] * c[r]) + rbf(lo[r] * s[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { lo[r] = ol[r]; hi[r] = oh[r]; }
+    }
+    bf16_t* dst;
+    if (sec == 0)
+      dst = (bf16_t*)a.C + (size_t)b * a.ldc + h * 128 + d;
+    else
+      dst = (sec == 1 ? a.Kc : a.Vc) + (size_t)b * a.c_bs + (size_t)h * a.c_hs + (size_t)slot * 128 + d;
+    u32x2 s0 = {pack2(lo[0], lo[1]), pack2(lo[2], lo[3])};
+    u32x2 s1 = {pack2(hi[0], hi[1]), pack2(hi[2], hi[3])};
+    *(u32x2*)dst = s0;
+    *(u32x2*)(dst + 64) = s1;
+  }
+}
+
+// Un-paired epilogues: tile `nt` of the unit (global n-tile index `ntile`), one wave.
+template <int NT, int EPI, int WAVES>
+__device__ __forceinline__ void epilogue_tile(const GemvArgs& a, const float (*red)[NT][64][4], int nt, int ntile, int lane) {
+  const int g = lane >> 4, b = lane & 15;
+  f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < WAVES; ++i) v += *(const f32x4*)&red[i][nt][lane][0];
+  const int n = ntile * 16 + 4 * g;
+  const bool live = b < a.M && n < a.Nvalid;
+  float y[4];
+  float bb[4] = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias && live) {
+    const u32x2 bv = *(const u32x2*)(a.bias + n);
+    bb[0] = lo_bf(bv[0]); bb[1] = hi_bf(bv[0]); bb[2] = lo_bf(bv[1]); bb[3] = hi_bf(bv[1]);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) y[r] = rbf(v[r] + bb[r]);
+  if constexpr (EPI == EPI_RESIDUAL) {
+    if (live) {
+      const u32x2 rv = *(const u32x2*)(a.R + (size_t)b * a.ldr + n);
+      y[0] += lo_bf(rv[0]); y[1] += hi_bf(rv[0]); y[2] += lo_bf(rv[1]); y[3] += hi_bf(rv[1]);
+    }
+    if (a.ssq_out) {   // sum of squares of the stored (bf16) values of this n-tile, per batch row
+      float s = 0.f;
+      if (live) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float t = rbf(y[r]); s += t * t; }
+      }
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      if (g == 0) a.ssq_out[b * (a.N >> 4) + ntile] = s;
+    }
+  } else if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y[r] = 0.5f * y[r] * (1.0f + erff(y[r] * 0.70710678118654752440f));
+  }
+  if (!live) return;
+  if constexpr (EPI == EPI_F32) {
+    *(f32x4*)((float*)a.C + (size_t)b * a.ldc + n) = f32x4{y[0], y[1], y[2], y[3]};
+  } else {
+    u32x2 st = {pack2(y[0], y[1]), pack2(y[2], y[3])};
+    *(u32x2*)((bf16_t*)a.C + (size_t)b * a.ldc + n) = st;
+  }
+}
+
 template <int NT, int EPI, int WAVES, int U, int KMODE>
 __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs a) {
   __shared__ __attribute__((aligned(16))) float red[WAVES][NT][64][4];
@@ -96,113 +204,142 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs a) {
   for (int nt = 0; nt < NT; ++nt) *(f32x4*)&red[w][nt][lane][0] = acc[nt];
   __syncthreads();
 
-  // lane holds column b = r16 (batch row), rows n = 16*tile + 4g + r of the D tile
-  const int b = r16;
   if constexpr (EPI == EPI_SWIGLU || EPI == EPI_ROPE_KV) {
-    static_assert((EPI != EPI_SWIGLU && EPI != EPI_ROPE_KV) || NT == 2, "paired tiles");
-    if (w != 0) return;
-    f32x4 t0 = f32x4{0.f, 0.f, 0.f, 0.f}, t1 = t0;
-#pragma unroll
-    for (int i = 0; i < WAVES; ++i) {
-      t0 += *(const f32x4*)&red[i][0][lane][0];
-      t1 += *(const f32x4*)&red[i][NT - 1][lane][0];
-    }
-    if (b >= a.M) return;
-    if constexpr (EPI == EPI_SWIGLU) {
-      const int n = blockIdx.x * 16 + 4 * g;
-      if (n >= a.Nvalid) return;
-      float o[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float gg = rbf(t0[r]);
-        const float s = rbf(gg * sigmoidf_(gg));
-        o[r] = s * rbf(t1[r]);
-      }
-      u32x2 st = {pack2(o[0], o[1]), pack2(o[2], o[3])};
-      *(u32x2*)((bf16_t*)a.C + (size_t)b * a.ldc + n) = st;
-    } else {
-      // rows were packed so that tile 0 holds head dims [d0, d0+16) and tile 1 their rotary partners [d0+64, ...)
-      const int pair = blockIdx.x;
-      const int hs = pair >> 2, d = (pair & 3) * 16 + 4 * g;
-      const int sec = hs / a.H, h = hs % a.H;
-      const int len = *a.cur_len;
-      const int pos_raw = len - 1 - a.kbeg[b];
-      const int pos = pos_raw < 0 ? 0 : (pos_raw >= a.maxpos ? a.maxpos - 1 : pos_raw);
-      const int slot = len - 1;
-      float lo[4], hi[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { lo[r] = rbf(t0[r]); hi[r] = rbf(t1[r]); }
-      if (sec < 2) {
-        const u32x2 cv = *(const u32x2*)(a.cos_tab + (size_t)pos * 64 + d);
-        const u32x2 sv = *(const u32x2*)(a.sin_tab + (size_t)pos * 64 + d);
-        const float c[4] = {lo_bf(cv[0]), hi_bf(cv[0]), lo_bf(cv[1]), hi_bf(cv[1])};
-        const float s[4] = {lo_bf(sv[0]), hi_bf(sv[0]), lo_bf(sv[1]), hi_bf(sv[1])};
-        float ol[4], oh[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          ol[r] = rbf(lo[r] * c[r]) + rbf(-hi[r] * s[r]);
-          oh[r] = rbf(hi[r] * c[r]) + rbf(lo[r] * s[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { lo[r] = ol[r]; hi[r] = oh[r]; }
-      }
-      bf16_t* dst;
-      if (sec == 0)
-        dst = (bf16_t*)a.C + (size_t)b * a.ldc + h * 128 + d;
-      else
-        dst = (sec == 1 ? a.Kc : a.Vc) + (size_t)b * a.c_bs + (size_t)h * a.c_hs + (size_t)slot * 128 + d;
-      u32x2 s0 = {pack2(lo[0], lo[1]), pack2(lo[2], lo[3])};
-      u32x2 s1 = {pack2(hi[0], hi[1]), pack2(hi[2], hi[3])};
-      *(u32x2*)dst = s0;
-      *(u32x2*)(dst + 64) = s1;
-    }
+    if (w == 0) epilogue_pair<NT, EPI, WAVES>(a, red, blockIdx.x, lane);
   } else {
-    if (w >= NT) return;
-    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < WAVES; ++i) v += *(const f32x4*)&red[i][w][lane][0];
-    const int n = (ntile0 + w) * 16 + 4 * g;
-    const bool live = b < a.M && n < a.Nvalid;
-    float y[4];
-    float bb[4] = {0.f, 0.f, 0.f, 0.f};
-    if (a.bias && live) {
-      const u32x2 bv = *(const u32x2*)(a.bias + n);
-      bb[0] = lo_bf(bv[0]); bb[1] = hi_bf(bv[0]); bb[2] = lo_bf(bv[1]); bb[3] = hi_bf(bv[1]);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) y[r] = rbf(v[r] + bb[r]);
-    if constexpr (EPI == EPI_RESIDUAL) {
-      if (live) {
-        const u32x2 rv = *(const u32x2*)(a.R + (size_t)b * a.ldr + n);
-        y[0] += lo_bf(rv[0]); y[1] += hi_bf(rv[0]); y[2] += lo_bf(rv[1]); y[3] += hi_bf(rv[1]);
-      }
-      if (a.ssq_out) {   // sum of squares of the stored (bf16) values of this n-tile, per batch row
-        float s = 0.f;
-        if (live) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { const float t = rbf(y[r]); s += t * t; }
-        }
-        s += __shfl_xor(s, 16, 64);
-        s += __shfl_xor(s, 32, 64);
-        if (g == 0) a.ssq_out[b * (a.N >> 4) + ntile0 + w] = s;
-      }
-    } else if constexpr (EPI == EPI_GELU) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) y[r] = 0.5f * y[r] * (1.0f + erff(y[r] * 0.70710678118654752440f));
-    }
-    if (!live) return;
-    if constexpr (EPI == EPI_F32) {
-      *(f32x4*)((float*)a.C + (size_t)b * a.ldc + n) = f32x4{y[0], y[1], y[2], y[3]};
-    } else {
-      u32x2 st = {pack2(y[0], y[1]), pack2(y[2], y[3])};
-      *(u32x2*)((bf16_t*)a.C + (size_t)b * a.ldc + n) = st;
-    }
+    if (w < NT) epilogue_tile<NT, EPI, WAVES>(a, red, w, ntile0 + w, lane);
   }
+}
+
+// Persistent form: a fixed grid (<= one workgroup per CU), each workgroup walks units u = blockIdx.x, + gridDim.x, ...
+// (unit = NT n-tiles) and every wave treats its k-tiles of ALL its units as ONE stream of loads: the register ping-pong
+// keeps running across unit boundaries, so the memory pipe of a CU never drains while a unit is reduced and written.
+// At a unit boundary each wave parks its partial tiles in LDS (two parities), one barrier, and ONE wave (rotating)
+// runs the epilogue while the others are already multiplying the next unit. Bytes in flight per CU are set by
+// WAVES * 2 * U * NT KiB and not by how many workgroups happen to share the CU.
+template <int NT, int EPI, int WAVES, int U>
+__global__ __launch_bounds__(WAVES * 64) void gemv_pers_kernel(GemvArgs a, int units) {
+  __shared__ __attribute__((aligned(16))) float red[2][WAVES][NT][64][4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, r16 = lane & 15;
+  const int KT = a.K >> 5;
+  const int nk = (KT - w + WAVES - 1) / WAVES;                       // >= 1 (host: KT >= WAVES)
+  const int G = gridDim.x;
+  const int nu = (units - (int)blockIdx.x + G - 1) / G;             // >= 1 (host: G <= units)
+  const int T = nu * nk;                                            // steps of this wave's stream
+  const bool row_ok = r16 < a.M;
+  const bf16_t* xp = a.X + (size_t)(row_ok ? r16 : 0) * a.ldx + g * 8;
+  const size_t unit_stride = (size_t)NT * KT * 512;                 // elements between consecutive units
+  const bf16_t* wbase = a.Wp + (size_t)blockIdx.x * unit_stride + lane * 8;
+
+  bf16x8 wA[U][NT], wB[U][NT];
+  u32x4 xA[U], xB[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wA[u][nt] = wB[u][nt] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+
+  // load cursor: step ls = (unit lj, k index li)
+  int ls = 0, li = 0;
+  const bf16_t* lw = wbase;                                         // weights of the load cursor's unit
+  auto wload = [&](bf16x8 (&dst)[U][NT], u32x4 (&xd)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      xd[u] = u32x4{0u, 0u, 0u, 0u};
+      if (ls < T) {                                                  // wave-uniform
+        const int kt = w + li * WAVES;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          dst[u][nt] = __builtin_nontemporal_load((const bf16x8*)(lw + ((size_t)nt * KT + kt) * 512));
+        if (row_ok) xd[u] = *(const u32x4*)(xp + kt * 32);
+        ++ls;
+        if (++li == nk) { li = 0; lw += (size_t)G * unit_stride; }
+      }
+    }
+  };
+  wload(wA, xA);
+  wload(wB, xB);
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int cs = 0, ci = 0, cj = 0;                                       // compute cursor
+  auto compute = [&](bf16x8 (&src)[U][NT], u32x4 (&xs)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (cs < T) {
+        const bf16x8 xf = __builtin_bit_cast(bf16x8, xs[u]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(src[u][nt], xf, acc[nt], 0, 0, 0);
+        ++cs;
+        if (++ci == nk) {                                            // unit cj complete: every wave passes here nu times
+          ci = 0;
+          float (*rp)[NT][64][4] = red[cj & 1];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            *(f32x4*)&rp[w][nt][lane][0] = acc[nt];
+            acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+          __syncthreads();
+          if (w == cj % WAVES) {
+            const int unit = blockIdx.x + cj * G;
+            if constexpr (EPI == EPI_SWIGLU || EPI == EPI_ROPE_KV) {
+              epilogue_pair<NT, EPI, WAVES>(a, rp, unit, lane);
+            } else {
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) epilogue_tile<NT, EPI, WAVES>(a, rp, nt, unit * NT + nt, lane);
+            }
+          }
+          ++cj;
+        }
+      }
+  };
+  while (cs < T) {
+    compute(wA, xA);
+    wload(wA, xA);
+    compute(wB, xB);
+    wload(wB, xB);
+  }
+}
+
+template <int NT, int EPI, int WAVES, int U>
+void go_pers(const GemvArgs& a, int ntiles, int grid, hipStream_t s) {
+  hipLaunchKernelGGL((gemv_pers_kernel<NT, EPI, WAVES, U>), dim3(grid), dim3(WAVES * 64), 0, s, a, ntiles / NT);
 }
 
 template <int NT, int EPI, int WAVES, int U, int KMODE>
 void go(const GemvArgs& a, int ntiles, hipStream_t s) {
   hipLaunchKernelGGL((gemv_kernel<NT, EPI, WAVES, U, KMODE>), dim3(ntiles / NT), dim3(WAVES * 64), 0, s, a);
+}
+
+// Tuned on MI355X with tools/decode_bench (M = 8, LLaMA-7B shapes). Shallow load queues win everywhere (deeper unrolls
+// oversubscribe the memory system: -10..-25 %); about 8 MiB in flight over the chip is the sweet spot.
+//   o, down (residual epilogue, N = 4096: 256 units)   one unit per workgroup, K split 16 ways
+//   qkv + rotary (384 units)                           one unit per workgroup, 4 waves, one k-tile per buffer (20.1 -> 18.8 us)
+//   gate/up (688), lm_head (1000)                      persistent: ceil(units / 256) units per workgroup, 12 / 8 waves
+//                                                      (30.8 -> 29.4 us, 41.4 -> 40.3 us)
+// Tried and removed: RMSNorm in the prologue of the persistent kernel (row scales from the partials, activation image in
+// LDS, rows <= 8; bit-identical to the separate launch). Kernel time +3.2 us (gate/up) / +2.8 us (qkv) against the
+// 4.7 us launch it replaces, and end to end 3.32 vs 3.29 ms/token: the small launch overlaps the neighbours' ramp.
+template <int NT, int EPI>
+hipError_t pick_default(const GemvArgs& a, int ntiles, hipStream_t s) {
+  const int units = ntiles / NT, KT = a.K >> 5;
+  const int per = (units + 255) / 256;
+  const int grid = (units + per - 1) / per;
+  // The K split (number of waves) depends on the SHAPE only, never on the row count: the fp32 summation order, and with
+  // it every output bit of a row, is the same alone and inside any batch.
+  if (units <= 256 || KT < 12) {
+    if (units <= 256) go<NT, EPI, 16, 1, 1>(a, ntiles, s);
+    else go<NT, EPI, 4, 2, 1>(a, ntiles, s);
+  } else if constexpr (EPI == EPI_ROPE_KV) {
+    go_pers<NT, EPI, 4, 1>(a, ntiles, units, s);
+  } else if constexpr (EPI == EPI_SWIGLU) {
+    go_pers<NT, EPI, 12, 1>(a, ntiles, grid, s);
+  } else {
+    go_pers<NT, EPI, 8, 1>(a, ntiles, grid, s);
+  }
+  return hipGetLastError();
 }
 
 template <int NT, int EPI>
@@ -227,11 +364,7 @@ hipError_t pick(const GemvArgs& a, int ntiles, int variant, hipStream_t s) {
     case 15: go<NT, EPI, 16, 1, 1>(a, ntiles, s); break;
 #endif
     default:
-      // tuned on MI355X with tools/decode_bench (M = 8): N <= 4096 wants the K split 16 ways, large N fewer waves;
-      // shallow load queues win in both cases (deeper unrolls oversubscribe the memory system: -10..-25 %)
-      if (ntiles / NT <= 256) go<NT, EPI, 16, 1, 1>(a, ntiles, s);
-      else go<NT, EPI, 4, 2, 1>(a, ntiles, s);
-      break;
+      return pick_default<NT, EPI>(a, ntiles, s);
   }
   return hipGetLastError();
 }
@@ -253,6 +386,39 @@ hipError_t launch_gemv_ex(const GemvArgs& a, int epi, int variant, hipStream_t s
   }
   return hipErrorInvalidValue;
 }
+
+#ifdef GEMV_ALL_VARIANTS
+namespace {
+template <int NT, int EPI>
+hipError_t pick_pers(const GemvArgs& a, int ntiles, int waves, int u, int grid, hipStream_t s) {
+  if (ntiles % NT || grid > ntiles / NT || (a.K >> 5) < waves) return hipErrorInvalidValue;
+  const int key = waves * 10 + u;
+  switch (key) {
+    case 41: go_pers<NT, EPI, 4, 1>(a, ntiles, grid, s); break;
+    case 42: go_pers<NT, EPI, 4, 2>(a, ntiles, grid, s); break;
+    case 81: go_pers<NT, EPI, 8, 1>(a, ntiles, grid, s); break;
+    case 82: go_pers<NT, EPI, 8, 2>(a, ntiles, grid, s); break;
+    case 121: go_pers<NT, EPI, 12, 1>(a, ntiles, grid, s); break;
+    case 122: go_pers<NT, EPI, 12, 2>(a, ntiles, grid, s); break;
+    case 161: go_pers<NT, EPI, 16, 1>(a, ntiles, grid, s); break;
+    case 162: go_pers<NT, EPI, 16, 2>(a, ntiles, grid, s); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+}  // namespace
+// tools/decode_bench only: the persistent kernel with explicit (waves, k-tiles per buffer, grid)
+hipError_t launch_gemv_pers(const GemvArgs& a, int epi, int waves, int u, int grid, hipStream_t s) {
+  const int ntiles = a.N / 16;
+  switch (epi) {
+    case EPI_RESIDUAL: return pick_pers<1, EPI_RESIDUAL>(a, ntiles, waves, u, grid, s);
+    case EPI_SWIGLU: return pick_pers<2, EPI_SWIGLU>(a, ntiles, waves, u, grid, s);
+    case EPI_ROPE_KV: return pick_pers<2, EPI_ROPE_KV>(a, ntiles, waves, u, grid, s);
+    case EPI_F32: return pick_pers<2, EPI_F32>(a, ntiles, waves, u, grid, s);
+  }
+  return hipErrorInvalidValue;
+}
+#endif
 
 hipError_t launch_gemv(const GemmArgs& g, int epi, hipStream_t s) {
   GemvArgs a = {};

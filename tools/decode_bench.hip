@@ -46,6 +46,7 @@ __global__ void fill_kernel(uint16_t* p, size_t n, uint32_t seed) {
 }
 
 struct Shape { const char* name; int N, K, epi; };
+hipError_t launch_gemv_pers(const GemvArgs& a, int epi, int waves, int u, int grid, hipStream_t s);
 
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 8;
@@ -147,6 +148,46 @@ int main(int argc, char** argv) {
       const int vi = variant - 1;
       if (variant == 0) printf("%s default    : %7.2f us  %7.1f GB/s\n", sh.name, us, wbytes / us * 1e-3);
       else printf("%s W%-2d U%d    : %7.2f us  %7.1f GB/s\n", sh.name, 1 << (vi / 3), variant == 15 ? 1 : 2 << (vi % 3), us, wbytes / us * 1e-3);
+    }
+  }
+  // ---- persistent GEMV: (waves, U, grid) sweep, checked against the default kernel's output
+  if (getenv("PERS_EXP")) {
+    for (const Shape& sh : shapes) {
+      const size_t wbytes = (size_t)sh.N * sh.K * 2;
+      GemvArgs a = {};
+      a.X = X; a.ldx = sh.K; a.bias = nullptr; a.R = R; a.ldr = sh.N; a.C = Y;
+      a.ldc = sh.epi == EPI_SWIGLU ? sh.N / 2 : (sh.epi == EPI_ROPE_KV ? d : sh.N);
+      a.M = M; a.N = sh.N; a.K = sh.K; a.Nvalid = sh.epi == EPI_SWIGLU ? sh.N / 2 : sh.N;
+      a.H = H; a.kbeg = ints + 16; a.cur_len = ints; a.cos_tab = cosb; a.sin_tab = sinb;
+      a.maxpos = 4096; a.Kc = Kc; a.Vc = Vc; a.c_bs = (long)H * Tmax * 128; a.c_hs = (long)Tmax * 128;
+      a.ssq_out = ssq;
+      const int units = sh.N / 16 / (sh.epi == EPI_RESIDUAL ? 1 : 2);
+      // reference output with the default kernel on fixed weights
+      const size_t out_bytes = (size_t)16 * 32000 * 4;
+      std::vector<char> ref(out_bytes), got(out_bytes);
+      a.Wp = pool;
+      CK(hipMemset(Y, 0, out_bytes));
+      CK(launch_gemv_ex(a, sh.epi, 0, s));
+      CK(hipMemcpy(ref.data(), Y, out_bytes, hipMemcpyDeviceToHost));
+      for (int waves : {4, 8, 12, 16})
+        for (int u : {1, 2})
+          for (int div : {1, 2, 3, 4, 5, 6, 8}) {
+            int grid = (units + div - 1) / div;
+            if (grid > 512 || grid < 64) continue;
+            a.Wp = pool;
+            CK(hipMemset(Y, 0, out_bytes));
+            hipError_t e0 = launch_gemv_pers(a, sh.epi, waves, u, grid, s);
+            if (e0 != hipSuccess) { (void)hipGetLastError(); continue; }
+            CK(hipMemcpy(got.data(), Y, out_bytes, hipMemcpyDeviceToHost));
+            const bool same = memcmp(ref.data(), got.data(), out_bytes) == 0;
+            float us = time_it([&](int i) {
+              const size_t off = ((size_t)i * wbytes) % (pool_bytes - wbytes);
+              a.Wp = (const bf16_t*)((char*)pool + (off & ~(size_t)1023));
+              CK(launch_gemv_pers(a, sh.epi, waves, u, grid, s));
+            });
+            printf("%s pers W%-2d U%d grid %4d (%d units/wg): %7.2f us  %7.1f GB/s  %s\n", sh.name, waves, u, grid, div, us, wbytes / us * 1e-3,
+                   same ? "same" : "DIFFERENT");
+          }
     }
   }
   // ---- does a prefetch of the head of W (Infinity Cache warm-up during the small norm launch) shorten the GEMV?
