@@ -99,7 +99,7 @@ def pmc_traffic():
         return None, None
     d = json.load(open(files[-1]))
     for k, v in d['kernels'].items():
-        if 'gemv_kernel<2, 4,' in k:
+        if 'gemv_pers_kernel<2, 4,' in k or 'gemv_kernel<2, 4,' in k:
             return v['hbm_bytes_per_launch'], os.path.relpath(files[-1], ROOT)
     return None, None
 
@@ -222,7 +222,7 @@ def main():
             'stage_ms': {'vision_fuse_splice': t_vis * 1e3, 'prefill': t_pre * 1e3, 'decode_total': t_dec * 1e3, 'decode_per_token': dec_ms},
             'decode_step': {'algorithmic_bytes': dec_bytes, 'achieved_GBps': dec_bytes / (dec_ms * 1e-3) / 1e9,
                             'frac_of_hbm_peak': dec_bytes / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-            'roofline': {'kernel': 'gemv_kernel<2,SWIGLU> (decode gate/up projection, 22016x4096 bf16 weights)', 'bound': 'hbm',
+            'roofline': {'kernel': 'gemv_pers_kernel<2,SWIGLU,12,1> (decode gate/up projection, 22016x4096 bf16 weights)', 'bound': 'hbm',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'traffic_source': traffic_src, 'launches_timed': prof_n, 'avg_launch_us': avg_us,
                          'algorithmic_bytes_per_launch': prof_bytes},
