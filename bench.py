@@ -128,10 +128,16 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    backend = os.environ.get('ORC_DIST_BACKEND', 'nccl')     # 'gloo': rehearsal of the N > 1 path on a one-GPU box
+    if backend != 'nccl':
+        local %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
     dims = FULL if a.dims == 'full' else TINY
 
     torch.manual_seed(1234 + rank)
@@ -154,7 +160,12 @@ def main():
                              chunk=a.new_tokens)
         new = out[:, input_ids.shape[1]:]
         if world > 1:
-            dist.all_gather_into_tensor(gathered, new.to(torch.int32).contiguous())
+            if backend == 'nccl':
+                dist.all_gather_into_tensor(gathered, new.to(torch.int32).contiguous())
+            else:
+                parts = [torch.empty(a.batch, a.new_tokens, dtype=torch.int32) for _ in range(world)]
+                dist.all_gather(parts, new.to(torch.int32).cpu().contiguous())
+                gathered.copy_(torch.cat(parts))
         return new
 
     def sync():
@@ -178,7 +189,7 @@ def main():
     eng.profile_enable(False)
     assert new.shape[1] == a.new_tokens, new.shape
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
