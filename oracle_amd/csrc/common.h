@@ -56,3 +56,9 @@ __device__ __forceinline__ float wave_max(float v) {
 // One wave-wide 16-byte load of a block is therefore a fully contiguous 1 KiB read, and the same
 // block copied linearly into LDS is read back conflict-free with ds_read_b128 at lane*16.
 __host__ __device__ __forceinline__ size_t packed_block_elems() { return 512; }
+
+// "Fragment-ordered" activation layout of the decode path (<= 16 rows): element (row b, input k) lives at
+// ((k / 8) * 16 + b) * 8 + k % 8, i.e. [k-chunk of 8][16 rows][8]. The MFMA B fragment of a k-tile (lane = (g, row): 8
+// elements at k = 32 kt + 8 g) is then ONE contiguous 1-KiB wave read (8 whole 128-B lines) instead of 16 half lines of
+// 16 different rows; every GEMV workgroup re-reads the whole activation through L2, so this halves its request count.
+__host__ __device__ __forceinline__ size_t xf_off(int b, int k) { return ((size_t)(k >> 3) * 16 + b) * 8 + (k & 7); }

@@ -605,9 +605,10 @@ extern "C" int orc_splice(orc_engine* e, const int32_t* codes, int rows, const v
 
 // ============================================================================ LLaMA
 static int gemv_ex(orc_engine* e, const bf16_t* X, int ldx, const Packed& W, const bf16_t* R, void* C, int ldc, int M, int epi,
-                   hipStream_t s, bf16_t* kc = nullptr, bf16_t* vc = nullptr, float* ssq_out = nullptr) {
+                   hipStream_t s, bf16_t* kc = nullptr, bf16_t* vc = nullptr, float* ssq_out = nullptr, int x_xf = 0, int c_xf = 0) {
   const orc_config& c = e->c;
   GemvArgs a = {};
+  a.x_xf = x_xf; a.c_xf = c_xf;
   a.X = X; a.ldx = ldx; a.Wp = W.p; a.bias = nullptr; a.R = R; a.ldr = ldc; a.C = C; a.ldc = ldc;
   a.M = M; a.N = W.N; a.K = W.K; a.Nvalid = (epi == EPI_SWIGLU) ? W.Nvalid / 2 : W.Nvalid;
   a.H = c.n_heads; a.kbeg = e->d_kbeg; a.cur_len = e->d_curlen; a.cos_tab = e->cos_tab; a.sin_tab = e->sin_tab;
@@ -650,7 +651,8 @@ static int llama_prefill_layers(orc_engine* e, bf16_t* h, bf16_t* xn, bf16_t* qk
   return 0;
 }
 
-// decode: 7 launches per layer --
+// decode: 7 launches per layer; the activations between them (d_xn, d_att, d_mlp) are kept in the fragment-ordered
+// layout of common.h xf_off, written so by their producers --
 //   [RMSNorm from partials] [qkv GEMV + rotary + KV write] [attention over the cache] [o_proj GEMV + residual + ssq partials]
 //   [RMSNorm from partials] [gate/up GEMV + SiLU*mul] [down GEMV + residual + ssq partials]
 // The residual epilogues leave per-n-tile sums of squares of the new hidden state in d_ssq, so the norms are
@@ -663,20 +665,21 @@ static int llama_decode_layers(orc_engine* e, int B, hipStream_t s) {
     const LlamaLayer& L = e->llama[i];
     bf16_t* kc = e->kcache + (size_t)i * e->kv_layer_elems;
     bf16_t* vc = e->vcache + (size_t)i * e->kv_layer_elems;
-    HIPCHK(launch_rmsnorm_part(h, d, e->d_ssq, np, L.ln_in, xn, d, B, d, c.rms_eps, s));
-    ORCCHK(gemv_ex(e, xn, d, L.qkv_dec, nullptr, q, d, B, EPI_ROPE_KV, s, kc, vc));
+    HIPCHK(launch_rmsnorm_part(h, d, e->d_ssq, np, L.ln_in, xn, d, B, d, c.rms_eps, s, 1));
+    ORCCHK(gemv_ex(e, xn, d, L.qkv_dec, nullptr, q, d, B, EPI_ROPE_KV, s, kc, vc, nullptr, 1));
     DecodeAttnArgs a;
+    a.o_xf = 1;
     a.Q = q; a.q_bs = d; a.Kc = kc; a.Vc = vc; a.c_bs = e->c_bs; a.c_hs = e->c_hs; a.O = att; a.o_bs = d;
     a.part = e->w_part; a.kbeg = e->d_kbeg; a.cur_len = e->d_curlen; a.B = B; a.H = c.n_heads;
     a.scale = 0.08838834764831845f;
     HIPCHK(launch_decode_attention(a, s));
-    ORCCHK(gemv_ex(e, att, d, L.o, h, h, d, B, EPI_RESIDUAL, s, nullptr, nullptr, e->d_ssq));
-    HIPCHK(launch_rmsnorm_part(h, d, e->d_ssq, np, L.ln_post, xn, d, B, d, c.rms_eps, s));
+    ORCCHK(gemv_ex(e, att, d, L.o, h, h, d, B, EPI_RESIDUAL, s, nullptr, nullptr, e->d_ssq, 1));
+    HIPCHK(launch_rmsnorm_part(h, d, e->d_ssq, np, L.ln_post, xn, d, B, d, c.rms_eps, s, 1));
     const bool sample = e->prof_on && (i % 8 == 0) && e->ev_used < (int)e->ev_a.size();
     if (sample) HIPCHK(hipEventRecord(e->ev_a[e->ev_used], s));
-    ORCCHK(gemv_ex(e, xn, d, L.gu, nullptr, mlp, c.d_ff, B, EPI_SWIGLU, s));
+    ORCCHK(gemv_ex(e, xn, d, L.gu, nullptr, mlp, c.d_ff, B, EPI_SWIGLU, s, nullptr, nullptr, nullptr, 1, 1));
     if (sample) HIPCHK(hipEventRecord(e->ev_b[e->ev_used++], s));
-    ORCCHK(gemv_ex(e, mlp, c.d_ff, L.down, h, h, d, B, EPI_RESIDUAL, s, nullptr, nullptr, e->d_ssq));
+    ORCCHK(gemv_ex(e, mlp, c.d_ff, L.down, h, h, d, B, EPI_RESIDUAL, s, nullptr, nullptr, e->d_ssq, 1));
   }
   return 0;
 }
@@ -685,10 +688,10 @@ static int llama_decode_layers(orc_engine* e, int B, hipStream_t s) {
 static int head_and_sample(orc_engine* e, const bf16_t* hrows, int ldh, int B, float* logits_out, bool from_decode, hipStream_t s) {
   const orc_config& c = e->c;
   if (from_decode)
-    HIPCHK(launch_rmsnorm_part(hrows, ldh, e->d_ssq, c.d_model / 16, e->final_norm, e->d_xn, c.d_model, B, c.d_model, c.rms_eps, s));
+    HIPCHK(launch_rmsnorm_part(hrows, ldh, e->d_ssq, c.d_model / 16, e->final_norm, e->d_xn, c.d_model, B, c.d_model, c.rms_eps, s, 1));
   else
     HIPCHK(launch_rmsnorm(hrows, ldh, e->final_norm, e->d_xn, c.d_model, B, c.d_model, c.rms_eps, s));
-  ORCCHK(gemv_ex(e, e->d_xn, c.d_model, e->lm_head, nullptr, e->w_logits, c.vocab, B, EPI_F32, s));
+  ORCCHK(gemv_ex(e, e->d_xn, c.d_model, e->lm_head, nullptr, e->w_logits, c.vocab, B, EPI_F32, s, nullptr, nullptr, nullptr, from_decode ? 1 : 0));
   if (logits_out)
     HIPCHK(hipMemcpyAsync(logits_out, e->w_logits, (size_t)B * c.vocab * 4, hipMemcpyDeviceToDevice, s));
   SampleArgs a;

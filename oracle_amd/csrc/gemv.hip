@@ -47,7 +47,7 @@ __device__ __forceinline__ void epilogue_pair(const GemvArgs& a, const float (*r
       o[r] = s * rbf(t1[r]);
     }
     u32x2 st = {pack2(o[0], o[1]), pack2(o[2], o[3])};
-    *(u32x2*)((bf16_t*)a.C + (size_t)b * a.ldc + n) = st;
+    *(u32x2*)((bf16_t*)a.C + (a.c_xf ? xf_off(b, n) : (size_t)b * a.ldc + n)) = st;
   } else {
     // rows were packed so that tile 0 holds head dims [d0, d0+16) and tile 1 their rotary partners [d0+64, ...)
     const int hs = pair >> 2, d = (pair & 3) * 16 + 4 * g;
@@ -149,7 +149,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs a) {
   }
   const bool row_ok = r16 < a.M;
 
-  const bf16_t* xp = a.X + (size_t)(row_ok ? r16 : 0) * a.ldx + g * 8;
+  const bf16_t* xp = a.x_xf ? a.X + (g * 16 + (row_ok ? r16 : 0)) * 8 : a.X + (size_t)(row_ok ? r16 : 0) * a.ldx + g * 8;
+  const int xstep = a.x_xf ? 512 : 32;                              // elements between this lane's fragments of consecutive k-tiles
   const bf16_t* wp[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) wp[nt] = a.Wp + (size_t)(ntile0 + nt) * KT * 512 + lane * 8;
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs a) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       xd[u] = u32x4{0u, 0u, 0u, 0u};
-      if (i + u < nk && row_ok) xd[u] = *(const u32x4*)(xp + (k0 + (i + u) * kstep) * 32);
+      if (i + u < nk && row_ok) xd[u] = *(const u32x4*)(xp + (size_t)(k0 + (i + u) * kstep) * xstep);
     }
   };
   wload(wA, xA, 0);
@@ -229,7 +230,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_pers_kernel(GemvArgs a, int u
   const int nu = (units - (int)blockIdx.x + G - 1) / G;             // >= 1 (host: G <= units)
   const int T = nu * nk;                                            // steps of this wave's stream
   const bool row_ok = r16 < a.M;
-  const bf16_t* xp = a.X + (size_t)(row_ok ? r16 : 0) * a.ldx + g * 8;
+  const bf16_t* xp = a.x_xf ? a.X + (g * 16 + (row_ok ? r16 : 0)) * 8 : a.X + (size_t)(row_ok ? r16 : 0) * a.ldx + g * 8;
+  const int xstep = a.x_xf ? 512 : 32;                              // elements between this lane's fragments of consecutive k-tiles
   const size_t unit_stride = (size_t)NT * KT * 512;                 // elements between consecutive units
   const bf16_t* wbase = a.Wp + (size_t)blockIdx.x * unit_stride + lane * 8;
 
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_pers_kernel(GemvArgs a, int u
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
           dst[u][nt] = __builtin_nontemporal_load((const bf16x8*)(lw + ((size_t)nt * KT + kt) * 512));
-        if (row_ok) xd[u] = *(const u32x4*)(xp + kt * 32);
+        if (row_ok) xd[u] = *(const u32x4*)(xp + (size_t)kt * xstep);
         ++ls;
         if (++li == nk) { li = 0; lw += (size_t)G * unit_stride; }
       }

@@ -34,6 +34,9 @@ struct GemvArgs {
   int H; const int* kbeg; const int* cur_len;
   const bf16_t* cos_tab; const bf16_t* sin_tab; int maxpos;
   bf16_t* Kc; bf16_t* Vc; long c_bs, c_hs;
+  // decode-path activation buffers in the fragment-ordered layout (common.h xf_off): x_xf = X is, c_xf = C is written so
+  // (EPI_SWIGLU only: its output feeds the down projection)
+  int x_xf, c_xf;
 };
 hipError_t launch_gemv_ex(const GemvArgs& a, int epi, int variant, hipStream_t s);
 hipError_t launch_pack_weight(const bf16_t* W, int Nsrc, int K, const int* rowmap, bf16_t* Wp, int Np, int Kp,
@@ -43,8 +46,9 @@ hipError_t launch_pack_weight(const bf16_t* W, int Nsrc, int K, const int* rowma
 hipError_t launch_rmsnorm(const bf16_t* x, int ldx, const bf16_t* w, bf16_t* y, int ldy, int rows, int d, float eps,
                           hipStream_t s);
 // RMSNorm with the row sums of squares supplied as n_part partials per row (part[row][n_part])
+// y_xf: y is written in the fragment-ordered layout (common.h xf_off) instead of [row][ldy]
 hipError_t launch_rmsnorm_part(const bf16_t* x, int ldx, const float* part, int n_part, const bf16_t* w, bf16_t* y, int ldy,
-                               int rows, int d, float eps, hipStream_t s);
+                               int rows, int d, float eps, hipStream_t s, int y_xf = 0);
 hipError_t launch_layernorm(const bf16_t* x, int ldx, const bf16_t* w, const bf16_t* b, bf16_t* y, int ldy, int rows,
                             int d, float eps, hipStream_t s);
 
@@ -74,6 +78,7 @@ struct DecodeAttnArgs {
   const int* cur_len;                        // device scalar: number of cached keys incl. the new one
   int B, H;
   float scale;
+  int o_xf;                                  // write O in the fragment-ordered layout (common.h xf_off), k = h * 128 + d
 };
 #define DECODE_NSPLIT 8   // capacity of the split-KV partial buffer; the launch picks 2..8 splits by batch
 hipError_t launch_decode_attention(const DecodeAttnArgs& a, hipStream_t s, int variant = 0);

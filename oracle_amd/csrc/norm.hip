@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__
 // grid (d / 1024, rows), 128 threads, 8 elements per thread: no row-wide reduction, many small workgroups.
 __global__ __launch_bounds__(128) void rmsnorm_part_kernel(const bf16_t* __restrict__ x, int ldx, const float* __restrict__ part,
                                                            int n_part, const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
-                                                           int ldy, int d, float eps) {
+                                                           int ldy, int d, float eps, int y_xf) {
   __shared__ float sh[2];
   const int row = blockIdx.y, c = blockIdx.x * 128 + threadIdx.x;
   const bool ok = c * 8 < d;
@@ -81,7 +81,8 @@ __global__ __launch_bounds__(128) void rmsnorm_part_kernel(const bf16_t* __restr
 #pragma unroll
   for (int j = 0; j < 4; ++j)
     o[j] = pack2(rbf(lo_bf(v[j]) * r) * lo_bf(wv[j]), rbf(hi_bf(v[j]) * r) * hi_bf(wv[j]));
-  *(u32x4*)(y + (size_t)row * ldy + c * 8) = o;
+  if (y_xf) *(u32x4*)(y + xf_off(row, c * 8)) = o;      // chunk c of 8 inputs, all 16 row slots side by side
+  else *(u32x4*)(y + (size_t)row * ldy + c * 8) = o;
 }
 
 // y = bf16( (x - mean) * rstd * w + b ), biased variance, stats fp32 (torch.nn.LayerNorm on bf16)
@@ -151,10 +152,10 @@ hipError_t launch_rmsnorm(const bf16_t* x, int ldx, const bf16_t* w, bf16_t* y, 
 }
 
 hipError_t launch_rmsnorm_part(const bf16_t* x, int ldx, const float* part, int n_part, const bf16_t* w, bf16_t* y, int ldy,
-                               int rows, int d, float eps, hipStream_t s) {
+                               int rows, int d, float eps, hipStream_t s, int y_xf) {
   if (rows <= 0) return hipSuccess;
-  if ((d & 7) || n_part <= 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(rmsnorm_part_kernel, dim3((d + 1023) / 1024, rows), dim3(128), 0, s, x, ldx, part, n_part, w, y, ldy, d, eps);
+  if ((d & 7) || n_part <= 0 || (y_xf && rows > 16)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(rmsnorm_part_kernel, dim3((d + 1023) / 1024, rows), dim3(128), 0, s, x, ldx, part, n_part, w, y, ldy, d, eps, y_xf);
   return hipGetLastError();
 }
 

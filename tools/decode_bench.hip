@@ -136,7 +136,7 @@ int main(int argc, char** argv) {
       a.M = M; a.N = sh.N; a.K = sh.K; a.Nvalid = sh.epi == EPI_SWIGLU ? sh.N / 2 : sh.N;
       a.H = H; a.kbeg = ints + 16; a.cur_len = ints; a.cos_tab = cosb; a.sin_tab = sinb;
       a.maxpos = 4096; a.Kc = Kc; a.Vc = Vc; a.c_bs = (long)H * Tmax * 128; a.c_hs = (long)Tmax * 128;
-      a.ssq_out = ssq;
+      a.ssq_out = ssq; a.x_xf = 1; a.c_xf = 1;
       hipError_t err = hipSuccess;
       float us = time_it([&](int i) {
         const size_t off = ((size_t)i * wbytes) % (pool_bytes - wbytes);
@@ -226,7 +226,8 @@ int main(int argc, char** argv) {
   }
   // ---- decode attention
   {
-    DecodeAttnArgs a;
+    DecodeAttnArgs a = {};
+    a.o_xf = 1;
     a.Q = X; a.q_bs = d; a.c_bs = (long)H * Tmax * 128; a.c_hs = (long)Tmax * 128; a.O = Y; a.o_bs = d;
     a.part = part; a.kbeg = ints + 16; a.cur_len = ints; a.B = M; a.H = H; a.scale = 0.0883883f;
     const size_t bytes = (size_t)M * H * ctx * 512;
@@ -245,21 +246,22 @@ int main(int argc, char** argv) {
     float us = time_it([&](int i) {
       char* base = (char*)pool + ((size_t)(i % 6) * layer_bytes);
       GemvArgs a = {};
-      a.bias = nullptr; a.M = M; a.H = H; a.kbeg = ints + 16; a.cur_len = ints;
+      a.bias = nullptr; a.M = M; a.H = H; a.kbeg = ints + 16; a.cur_len = ints; a.x_xf = 1; a.c_xf = 1;
       a.cos_tab = cosb; a.sin_tab = sinb; a.maxpos = 4096; a.c_bs = (long)H * Tmax * 128; a.c_hs = (long)Tmax * 128;
       a.Kc = Kc + (size_t)(i % 8) * kv_elems; a.Vc = Vc + (size_t)(i % 8) * kv_elems;
       bf16_t* xn = R + (size_t)8 * ff;   // scratch rows
-      CK(launch_rmsnorm_part(X, d, ssq, 256, lnw, xn, d, M, d, 1e-5f, s));
+      CK(launch_rmsnorm_part(X, d, ssq, 256, lnw, xn, d, M, d, 1e-5f, s, 1));
       a.X = xn; a.ldx = d; a.Wp = (const bf16_t*)base; a.C = Y; a.ldc = d; a.N = 3 * d; a.K = d; a.Nvalid = 3 * d; a.R = nullptr;
       CK(launch_gemv_ex(a, EPI_ROPE_KV, 0, s));
-      DecodeAttnArgs t;
+      DecodeAttnArgs t = {};
+      t.o_xf = 1;
       t.Q = Y; t.q_bs = d; t.Kc = a.Kc; t.Vc = a.Vc; t.c_bs = a.c_bs; t.c_hs = a.c_hs; t.O = R; t.o_bs = d;
       t.part = part; t.kbeg = ints + 16; t.cur_len = ints; t.B = M; t.H = H; t.scale = 0.0883883f;
       CK(launch_decode_attention(t, s));
       a.X = R; a.Wp = (const bf16_t*)(base + (size_t)3 * d * d * 2); a.C = X; a.R = X; a.ldr = d; a.ldc = d; a.N = d; a.Nvalid = d;
       a.ssq_out = ssq;
       CK(launch_gemv_ex(a, EPI_RESIDUAL, 0, s));
-      CK(launch_rmsnorm_part(X, d, ssq, 256, lnw, xn, d, M, d, 1e-5f, s));
+      CK(launch_rmsnorm_part(X, d, ssq, 256, lnw, xn, d, M, d, 1e-5f, s, 1));
       a.X = xn; a.Wp = (const bf16_t*)(base + (size_t)4 * d * d * 2); a.C = Y; a.ldc = ff; a.N = 2 * ff; a.Nvalid = ff; a.R = nullptr;
       a.ssq_out = nullptr;
       CK(launch_gemv_ex(a, EPI_SWIGLU, 0, s));
