@@ -831,8 +831,10 @@ extern "C" int orc_test_gemm(const void* x, int M, int K, const void* w, int N, 
   a.X = (const bf16_t*)x; a.ldx = K; a.Wp = wp; a.bias = (const bf16_t*)bias; a.R = (const bf16_t*)residual;
   const int nout = epi == EPI_SWIGLU ? N / 2 : N;
   a.ldr = nout; a.C = out; a.ldc = nout; a.M = M; a.N = Np; a.K = Kp; a.Nvalid = nout;
-  // use_gemv: 0 = GEMM (automatic kernel choice), 1 = decode GEMV, 2 = 128^2 register-staged GEMM, 3 / 4 = LDS-DMA GEMM BM 256 / 128
-  if (use_gemv >= 2) gemm_force_kernel(use_gemv - 1);
+  // use_gemv: 0 = GEMM (automatic kernel choice), 1 = decode GEMV, 2 = 128^2 register-staged GEMM, 3 / 4 = LDS-DMA GEMM with
+  // 256-row / 128-row tiles only, 100 + n = LDS-DMA GEMM with n 256-row m-tiles and 128-row tiles for the remaining rows
+  if (use_gemv >= 100) gemm_force_kernel(use_gemv);
+  else if (use_gemv >= 2) gemm_force_kernel(use_gemv - 1);
   hipError_t err = use_gemv == 1 ? launch_gemv(a, epi, s) : launch_gemm(a, epi, s);
   gemm_force_kernel(0);
   if (err != hipSuccess) return fail("orc_test_gemm", hipGetErrorString(err));

@@ -12,6 +12,10 @@
 //
 // Epilogues reproduce the rounding points of the reference's eager bf16 graph (each torch op rounds its
 // output to bf16): Linear -> [QuickGELU | GELU(erf) | + residual | SiLU(gate) * up] -> bf16.
+#include <map>
+#include <queue>
+#include <utility>
+#include <vector>
 #include "common.h"
 #include "kernels.h"
 
@@ -187,9 +191,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs a) {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
 
+// One BM x 256 output tile. `t` = index of the tile inside its class (all tiles of one height), `ntiles` = tiles in the
+// class, rows of the class start at `m_base` and MT m-tiles of BM rows cover it.
 template <int BM, int EPI>
-__global__ __launch_bounds__(512) void gemm_dma_kernel(GemmArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void gemm_dma_tile(const GemmArgs& a, char* smem, int bid, int nwg, int m_base, int MT) {
   constexpr int XB = BM * 128;              // bytes of the X part of a stage
   constexpr int STAGE = XB + 256 * 128;     // + W part
   constexpr int MTW = BM / 32;              // 16-row m-tiles per wave
@@ -198,15 +203,14 @@ __global__ __launch_bounds__(512) void gemm_dma_kernel(GemmArgs a) {
   const int wm = w >> 2, wn = w & 3;
   const int g = lane >> 4, r16 = lane & 15;
 
-  const int MT = (a.M + BM - 1) / BM, NTt = a.N >> 8;
-  const int bid = blockIdx.x, nwg = gridDim.x;
+  const int NTt = a.N >> 8;
   const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
   const int t = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
   constexpr int GM = 4;                     // 32 tiles run per XCD at once: 4 (m) x 8 (n)
   const int grp = t / (GM * NTt), rin = t % (GM * NTt);
   const int gm = (MT - grp * GM) < GM ? (MT - grp * GM) : GM;
   const int tm = grp * GM + rin % gm, tn = rin / gm;
-  const int m0 = tm * BM, n0 = tn << 8;
+  const int m0 = m_base + tm * BM, n0 = tn << 8;
   const int KT = a.K >> 5, nk = a.K >> 6;
 
   // per-lane DMA sources
@@ -224,6 +228,14 @@ __global__ __launch_bounds__(512) void gemm_dma_kernel(GemmArgs a) {
     const int b = i * 8 + w;                                  // block b = (n-tile b>>1, k-tile b&1)
     wsrc[i] = a.Wp + ((size_t)((n0 >> 4) + (b >> 1)) * KT + (b & 1)) * 512 + lane * 8;
   }
+  // instruction pair i of a stage's DMA (X rows (8 i + w) * 8 .., W block 8 i + w); XI == 4 for BM = 256
+  auto dma_pair = [&](int kt64, int stage, int i) {
+    char* sx = smem + stage * STAGE;
+    char* sw = sx + XB;
+    if (i < XI)
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(xsrc[i] + kt64 * 64), (lds_void_t*)(sx + (i * 8 + w) * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_void_t*)(wsrc[i] + (size_t)kt64 * 1024), (lds_void_t*)(sw + (i * 8 + w) * 1024), 16, 0, 0);
+  };
   auto dma = [&](int kt64, int stage) {
     char* sx = smem + stage * STAGE;
     char* sw = sx + XB;
@@ -246,7 +258,12 @@ __global__ __launch_bounds__(512) void gemm_dma_kernel(GemmArgs a) {
     const int st = kt & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // my DMA of this stage has landed
     __syncthreads();                                          // everyone's has, and everyone left the other stage
-    if (kt + 1 < nk) dma(kt + 1, st ^ 1);
+    // BM = 256: the next tile's 8 DMA instructions go out in pairs behind the first four m-tiles' MFMAs instead of as
+    // one burst behind the barrier. Every CU bursting 64 KB at the same moment left 49 % of wave time in s_waitcnt
+    // (PMC); spread, the same loads cost 8-12 % less kernel time. BM = 128 has half the MFMAs per k-step to hide a
+    // later issue behind and is 10 % slower spread, so it keeps the burst.
+    constexpr bool kSpread = MTW == 8;
+    if (!kSpread && kt + 1 < nk) dma(kt + 1, st ^ 1);
     const char* sx = smem + st * STAGE;
     const char* sw = sx + XB;
     // W fragments of the whole k-step stay in registers; X fragments stream one 16-row m-tile at a time, the next
@@ -276,6 +293,10 @@ __global__ __launch_bounds__(512) void gemm_dma_kernel(GemmArgs a) {
       // reads to just before their use and waits on them with the matrix pipe idle)
       if (mt + 1 < MTW) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      if (kSpread && mt < 4 && kt + 1 < nk) {
+        dma_pair(kt + 1, st ^ 1, mt);
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+      }
     }
   }
 
@@ -367,6 +388,21 @@ __global__ __launch_bounds__(512) void gemm_dma_kernel(GemmArgs a) {
   }
 }
 
+// Mixed-height launch: workgroups [0, n_big) compute 256-row tiles of rows [0, m_split), the rest 128-row tiles of rows
+// [m_split, M). The hardware hands the short tiles to CUs as they come free, so the partial last round of the tall tiles
+// is back-filled instead of idling (384 tall tiles on 256 CUs = 2 rounds, the second half empty: o_proj / down at 5912 rows).
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_dma_kernel(GemmArgs a, int n_big, int m_split) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int bid = blockIdx.x;
+  if (bid < n_big) {
+    gemm_dma_tile<256, EPI>(a, smem, bid, n_big, 0, n_big / (a.N >> 8));
+  } else {
+    const int nwg = gridDim.x - n_big;
+    gemm_dma_tile<128, EPI>(a, smem, bid - n_big, nwg, m_split, nwg / (a.N >> 8));
+  }
+}
+
 // W[Nsrc][K] row-major (optionally through rowmap: packed row -> source row, -1 = zero row)
 // -> packed blocks [Np/16][Kp/32][64 lanes][8].
 __global__ void pack_weight_kernel(const bf16_t* __restrict__ W, int Nsrc, int K, const int* __restrict__ rowmap,
@@ -391,33 +427,64 @@ __global__ void pack_weight_kernel(const bf16_t* __restrict__ W, int Nsrc, int K
   }
 }
 
-template <int BM, int EPI>
-hipError_t launch_dma_t(const GemmArgs& a, hipStream_t s) {
+// Number of 256-row m-tiles (the rest of the rows gets 128-row tiles) that minimises the makespan of greedy dispatch on
+// 256 CUs, tall tiles first. A 128-row tile costs kShort of a 256-row one (tools/gemm_bench: 0.58).
+static int plan_tall_tiles(int M, int N) {
+  static std::map<std::pair<int, int>, int> cache;
+  auto it = cache.find({M, N});
+  if (it != cache.end()) return it->second;
+  const int NT = N / 256, max_tall = (M + 255) / 256;
+  const double kShort = 0.58;
+  double best = 1e30;
+  int best_a = max_tall;
+  for (int a = max_tall; a >= 0; --a) {
+    const int rows_b = M - a * 256;
+    const int mtb = rows_b > 0 ? (rows_b + 127) / 128 : 0;
+    if (a < max_tall && rows_b <= 0) continue;
+    std::priority_queue<double, std::vector<double>, std::greater<double>> cu;
+    for (int i = 0; i < 256; ++i) cu.push(0.0);
+    double span = 0.0;
+    auto run = [&](long n, double cost) {
+      for (long i = 0; i < n; ++i) {
+        const double t = cu.top() + cost;
+        cu.pop();
+        cu.push(t);
+        if (t > span) span = t;
+      }
+    };
+    run((long)a * NT, 1.0);
+    run((long)mtb * NT, kShort);
+    if (span < best - 1e-9) { best = span; best_a = a; }
+  }
+  cache[{M, N}] = best_a;
+  return best_a;
+}
+
+template <int EPI>
+hipError_t launch_dma_t(const GemmArgs& a, int tall, hipStream_t s) {   // tall = number of 256-row m-tiles
   static bool attr_set = false;
-  constexpr int stages = 2 * (BM * 128 + 256 * 128), epi = 8 * (BM / 2) * 144;
+  constexpr int stages = 2 * (256 * 128 + 256 * 128), epi = 8 * 128 * 144;
   constexpr int lds = stages > epi ? stages : epi;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<BM, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  const int MT = (a.M + BM - 1) / BM, NT = a.N / 256;
-  hipLaunchKernelGGL((gemm_dma_kernel<BM, EPI>), dim3(MT * NT), dim3(512), lds, s, a);
+  const int NT = a.N / 256;
+  const int m_split = tall * 256 < a.M ? tall * 256 : a.M;
+  const int rows_b = a.M - m_split;
+  const int mtb = rows_b > 0 ? (rows_b + 127) / 128 : 0;
+  hipLaunchKernelGGL((gemm_dma_kernel<EPI>), dim3((tall + mtb) * NT), dim3(512), lds, s, a, tall * NT, m_split);
   return hipGetLastError();
 }
 
 template <int EPI>
 hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
   if ((a.M > 128 || g_gemm_force >= 2) && (a.N & 255) == 0 && g_gemm_force != 1) {
-    // tile height by whole-chip rounds: work done / work paid for over ceil(tiles / 256 CUs) rounds
-    auto eff = [&](int bm) {
-      const long tiles = (long)((a.M + bm - 1) / bm) * (a.N / 256);
-      const long rounds = (tiles + 255) / 256;
-      return (double)a.M * a.N / ((double)rounds * 256 * bm * 256);
-    };
-    // a 128-row tile runs at ~0.88x the per-tile rate of a 256-row one (tools/gemm_bench), so it must win that back in rounds
-    if (g_gemm_force == 2 || (g_gemm_force == 0 && eff(256) >= 0.88 * eff(128))) return launch_dma_t<256, EPI>(a, s);   // force 3 -> BM 128
-    return launch_dma_t<128, EPI>(a, s);
+    // force 2: 256-row tiles only, 3: 128-row tiles only, 0: the mix that plan_tall_tiles picks
+    if (g_gemm_force >= 100) return launch_dma_t<EPI>(a, g_gemm_force - 100 < (a.M + 255) / 256 ? g_gemm_force - 100 : (a.M + 255) / 256, s);   // tools/gemm_bench: explicit count
+    const int tall = g_gemm_force == 2 ? (a.M + 255) / 256 : (g_gemm_force == 3 ? 0 : plan_tall_tiles(a.M, a.N));
+    return launch_dma_t<EPI>(a, tall, s);
   }
   static bool attr_set = false;
   if (!attr_set) {

@@ -67,7 +67,7 @@ def test_gemm_shapes(K, N):
     assert rel_err(out2, ref[:8]) <= TOL
 
 
-@pytest.mark.parametrize('kernel', ['tile128', 'dma256', 'dma128'])
+@pytest.mark.parametrize('kernel', ['tile128', 'dma256', 'dma128', 'mix2', 'mix1'])
 @pytest.mark.parametrize('epi', ['none', 'quickgelu', 'gelu', 'residual', 'swiglu', 'f32'])
 def test_gemm_kernels_agree(kernel, epi):
     """Every large-M GEMM kernel (register-staged 128^2; LDS-DMA BM x 256) against torch, ragged M and padded N."""
