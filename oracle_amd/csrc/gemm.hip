@@ -13,7 +13,6 @@
 // Epilogues reproduce the rounding points of the reference's eager bf16 graph (each torch op rounds its
 // output to bf16): Linear -> [QuickGELU | GELU(erf) | + residual | SiLU(gate) * up] -> bf16.
 #include <map>
-#include <queue>
 #include <utility>
 #include <vector>
 #include "common.h"
@@ -427,35 +426,44 @@ __global__ void pack_weight_kernel(const bf16_t* __restrict__ W, int Nsrc, int K
   }
 }
 
-// Number of 256-row m-tiles (the rest of the rows gets 128-row tiles) that minimises the makespan of greedy dispatch on
-// 256 CUs, tall tiles first. A 128-row tile costs kShort of a 256-row one (tools/gemm_bench: 0.58).
+// Number of 256-row m-tiles (the rest of the rows gets 128-row tiles) that minimises the makespan of greedy in-order
+// dispatch on 256 CUs, tall tiles first. Costs in integer units: tall tile 100, short tile 58 (tools/gemm_bench).
+// Prompt lengths differ from call to call, so this runs for many (M, N): the dispatch is evaluated in closed form over
+// groups of equally loaded CUs (a few dozen steps per candidate) and only splits inside the last tall round are tried.
+static long greedy_makespan(long n_tall, long n_short) {
+  constexpr int kCUs = 256, kTall = 100, kShort = 58;
+  std::map<long, long> load;                         // load -> number of CUs carrying it
+  const long q = n_tall / kCUs, r = n_tall % kCUs;
+  if (r) load[(q + 1) * kTall] = r;
+  load[q * kTall] += kCUs - r;
+  long span = (q + (r ? 1 : 0)) * kTall;
+  while (n_short > 0) {
+    auto lo = load.begin();
+    const long l = lo->first, c = lo->second, take = n_short < c ? n_short : c;
+    if (take == c) load.erase(lo); else lo->second = c - take;
+    load[l + kShort] += take;
+    if (l + kShort > span) span = l + kShort;
+    n_short -= take;
+  }
+  return span;
+}
+
 static int plan_tall_tiles(int M, int N) {
-  static std::map<std::pair<int, int>, int> cache;
+  static std::map<std::pair<int, int>, int> cache;   // launches come from one host thread per process
   auto it = cache.find({M, N});
   if (it != cache.end()) return it->second;
   const int NT = N / 256, max_tall = (M + 255) / 256;
-  const double kShort = 0.58;
-  double best = 1e30;
+  const int window = 256 / NT + 2;                   // m-tiles that make up one round of tall tiles, and a little
+  long best = -1;
   int best_a = max_tall;
-  for (int a = max_tall; a >= 0; --a) {
+  for (int a = max_tall; a >= 0 && a >= max_tall - window; --a) {
     const int rows_b = M - a * 256;
-    const int mtb = rows_b > 0 ? (rows_b + 127) / 128 : 0;
     if (a < max_tall && rows_b <= 0) continue;
-    std::priority_queue<double, std::vector<double>, std::greater<double>> cu;
-    for (int i = 0; i < 256; ++i) cu.push(0.0);
-    double span = 0.0;
-    auto run = [&](long n, double cost) {
-      for (long i = 0; i < n; ++i) {
-        const double t = cu.top() + cost;
-        cu.pop();
-        cu.push(t);
-        if (t > span) span = t;
-      }
-    };
-    run((long)a * NT, 1.0);
-    run((long)mtb * NT, kShort);
-    if (span < best - 1e-9) { best = span; best_a = a; }
+    const int mtb = rows_b > 0 ? (rows_b + 127) / 128 : 0;
+    const long span = greedy_makespan((long)a * NT, (long)mtb * NT);
+    if (best < 0 || span < best) { best = span; best_a = a; }
   }
+  if (cache.size() > 4096) cache.clear();
   cache[{M, N}] = best_a;
   return best_a;
 }
