@@ -10,7 +10,7 @@ the timed region. Multi-GPU: frames are sharded (one engine replica per rank, we
 an RCCL all-gather of the generated token ids per step.
 
 Prints ONE JSON line (rank 0). Extra objects: "roofline" for the dominant kernel (gate/up projection GEMV of decode,
-HBM-bound; duration from HIP events recorded on the launch stream inside the timed region) and "cpu_baseline"
+HBM-bound; duration from HIP start/stop events attached to the launches themselves on the launch stream, inside the timed region) and "cpu_baseline"
 (the CPU oracle timed on this host's cores on a bounded, stated sample).
 """
 import argparse

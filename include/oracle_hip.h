@@ -110,8 +110,8 @@ int orc_test_layernorm(const void* x, const void* w, const void* b, int rows, in
 int orc_test_attention(const void* q, const void* k, const void* v, int B, int H, int Sq, int Sk, int head_dim,
                        const int32_t* kbeg, const int32_t* kend, int causal, int q_off, float scale, void* out,
                        void* stream);
-/* HIP-event sampling of the dominant decode kernel (gate/up projection GEMV of every 8th layer), recorded on
- * the stream the kernel is launched on. enable(1) resets the samples; read() synchronises the device and returns
+/* HIP-event sampling of the dominant decode kernel (gate/up projection GEMV of every 8th layer): start / stop events
+ * attached to the launch itself (the dispatch's timestamps) on the stream the kernel is launched on. enable(1) resets the samples; read() synchronises the device and returns
  * the summed duration, the number of sampled launches and the algorithmic bytes of one launch. */
 int orc_profile_enable(orc_engine* e, int on);
 int orc_profile_read(orc_engine* e, double* total_ms, int32_t* count, int64_t* bytes_per_launch);

@@ -605,10 +605,11 @@ extern "C" int orc_splice(orc_engine* e, const int32_t* codes, int rows, const v
 
 // ============================================================================ LLaMA
 static int gemv_ex(orc_engine* e, const bf16_t* X, int ldx, const Packed& W, const bf16_t* R, void* C, int ldc, int M, int epi,
-                   hipStream_t s, bf16_t* kc = nullptr, bf16_t* vc = nullptr, float* ssq_out = nullptr, int x_xf = 0, int c_xf = 0) {
+                   hipStream_t s, bf16_t* kc = nullptr, bf16_t* vc = nullptr, float* ssq_out = nullptr, int x_xf = 0, int c_xf = 0,
+                   hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
   const orc_config& c = e->c;
   GemvArgs a = {};
-  a.x_xf = x_xf; a.c_xf = c_xf;
+  a.x_xf = x_xf; a.c_xf = c_xf; a.ev_start = ev_start; a.ev_stop = ev_stop;
   a.X = X; a.ldx = ldx; a.Wp = W.p; a.bias = nullptr; a.R = R; a.ldr = ldc; a.C = C; a.ldc = ldc;
   a.M = M; a.N = W.N; a.K = W.K; a.Nvalid = (epi == EPI_SWIGLU) ? W.Nvalid / 2 : W.Nvalid;
   a.H = c.n_heads; a.kbeg = e->d_kbeg; a.cur_len = e->d_curlen; a.cos_tab = e->cos_tab; a.sin_tab = e->sin_tab;
@@ -676,9 +677,11 @@ static int llama_decode_layers(orc_engine* e, int B, hipStream_t s) {
     ORCCHK(gemv_ex(e, att, d, L.o, h, h, d, B, EPI_RESIDUAL, s, nullptr, nullptr, e->d_ssq, 1));
     HIPCHK(launch_rmsnorm_part(h, d, e->d_ssq, np, L.ln_post, xn, d, B, d, c.rms_eps, s, 1));
     const bool sample = e->prof_on && (i % 8 == 0) && e->ev_used < (int)e->ev_a.size();
-    if (sample) HIPCHK(hipEventRecord(e->ev_a[e->ev_used], s));
-    ORCCHK(gemv_ex(e, xn, d, L.gu, nullptr, mlp, c.d_ff, B, EPI_SWIGLU, s, nullptr, nullptr, nullptr, 1, 1));
-    if (sample) HIPCHK(hipEventRecord(e->ev_b[e->ev_used++], s));
+    // sampled launches carry their own start / stop events (the dispatch's timestamps, not a pair of event commands
+    // around it, which would add the launch boundary)
+    ORCCHK(gemv_ex(e, xn, d, L.gu, nullptr, mlp, c.d_ff, B, EPI_SWIGLU, s, nullptr, nullptr, nullptr, 1, 1,
+                   sample ? e->ev_a[e->ev_used] : nullptr, sample ? e->ev_b[e->ev_used] : nullptr));
+    if (sample) ++e->ev_used;
     ORCCHK(gemv_ex(e, mlp, c.d_ff, L.down, h, h, d, B, EPI_RESIDUAL, s, nullptr, nullptr, e->d_ssq, 1));
   }
   return 0;

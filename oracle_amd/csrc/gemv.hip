@@ -15,6 +15,7 @@
 // RMSNorm itself is NOT fused into the GEMV prologue: every workgroup would re-normalise the whole activation
 // (measured +11 us of VALU on the 180 MB gate/up launch vs +3.5 us for the separate small launch).
 // Every epilogue reproduces the reference's bf16 rounding points.
+#include <hip/hip_ext.h>
 #include "common.h"
 #include "kernels.h"
 
@@ -307,12 +308,20 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_pers_kernel(GemvArgs a, int u
 
 template <int NT, int EPI, int WAVES, int U>
 void go_pers(const GemvArgs& a, int ntiles, int grid, hipStream_t s) {
-  hipLaunchKernelGGL((gemv_pers_kernel<NT, EPI, WAVES, U>), dim3(grid), dim3(WAVES * 64), 0, s, a, ntiles / NT);
+  if (a.ev_start)
+    hipExtLaunchKernelGGL((gemv_pers_kernel<NT, EPI, WAVES, U>), dim3(grid), dim3(WAVES * 64), 0, s, (hipEvent_t)a.ev_start,
+                          (hipEvent_t)a.ev_stop, 0, a, ntiles / NT);
+  else
+    hipLaunchKernelGGL((gemv_pers_kernel<NT, EPI, WAVES, U>), dim3(grid), dim3(WAVES * 64), 0, s, a, ntiles / NT);
 }
 
 template <int NT, int EPI, int WAVES, int U, int KMODE>
 void go(const GemvArgs& a, int ntiles, hipStream_t s) {
-  hipLaunchKernelGGL((gemv_kernel<NT, EPI, WAVES, U, KMODE>), dim3(ntiles / NT), dim3(WAVES * 64), 0, s, a);
+  if (a.ev_start)
+    hipExtLaunchKernelGGL((gemv_kernel<NT, EPI, WAVES, U, KMODE>), dim3(ntiles / NT), dim3(WAVES * 64), 0, s, (hipEvent_t)a.ev_start,
+                          (hipEvent_t)a.ev_stop, 0, a);
+  else
+    hipLaunchKernelGGL((gemv_kernel<NT, EPI, WAVES, U, KMODE>), dim3(ntiles / NT), dim3(WAVES * 64), 0, s, a);
 }
 
 // Tuned on MI355X with tools/decode_bench (M = 8, LLaMA-7B shapes). Shallow load queues win everywhere (deeper unrolls

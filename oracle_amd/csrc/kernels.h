@@ -37,6 +37,9 @@ struct GemvArgs {
   // decode-path activation buffers in the fragment-ordered layout (common.h xf_off): x_xf = X is, c_xf = C is written so
   // (EPI_SWIGLU only: its output feeds the down projection)
   int x_xf, c_xf;
+  // optional (host side only): HIP events that bracket exactly this kernel's execution (hipExtLaunchKernelGGL start /
+  // stop events = the dispatch's own timestamps, what rocprofv3's kernel trace reports), for orc_profile_read
+  void* ev_start; void* ev_stop;
 };
 hipError_t launch_gemv_ex(const GemvArgs& a, int epi, int variant, hipStream_t s);
 hipError_t launch_pack_weight(const bf16_t* W, int Nsrc, int K, const int* rowmap, bf16_t* Wp, int Np, int Kp,
