@@ -262,14 +262,14 @@ __global__ __launch_bounds__(128) void resize_v_kernel(const uint8_t* __restrict
 // Block 0 of the LAST-arriving... no cross-block dependency is needed: per-row state only; the scalar
 // counters are advanced by row 0's block after every row has been read by its own block (each block
 // touches only its row, the counters are only read by LATER kernels of the step).
-__global__ __launch_bounds__(256) void argmax_sample_kernel(SampleArgs a) {
-  __shared__ float sv[4];
-  __shared__ int si[4];
+__global__ __launch_bounds__(1024) void argmax_sample_kernel(SampleArgs a) {   // 16 waves per row: 8 loads per thread at 32000
+  __shared__ float sv[16];
+  __shared__ int si[16];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const float* lg = a.logits + (size_t)b * a.vocab;
   float best = -INFINITY;
   int bi = 0x7fffffff;
-  for (int i = tid * 4; i < a.vocab; i += 1024) {
+  for (int i = tid * 4; i < a.vocab; i += 4096) {
     const f32x4 v = *(const f32x4*)(lg + i);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void argmax_sample_kernel(SampleArgs a) {
   if (lane == 0) { sv[w] = best; si[w] = bi; }
   __syncthreads();
   if (tid == 0) {
-    for (int i = 1; i < 4; ++i)
+    for (int i = 1; i < 16; ++i)
       if (sv[i] > best || (sv[i] == best && si[i] < bi)) { best = sv[i]; bi = si[i]; }
     if (bi == 0x7fffffff) bi = 0;   // all-NaN row: torch.argmax would return the first NaN; keep defined
     const int step = *a.step;
@@ -377,7 +377,7 @@ hipError_t launch_preprocess(const uint8_t* img, int n, int H, int W, int out, c
 }
 hipError_t launch_argmax_sample(const SampleArgs& a, hipStream_t s) {
   if ((a.vocab & 3) || a.B <= 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(argmax_sample_kernel, dim3(a.B), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(argmax_sample_kernel, dim3(a.B), dim3(1024), 0, s, a);
   hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, s, a);
   return hipGetLastError();
 }
