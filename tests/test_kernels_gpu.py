@@ -160,3 +160,22 @@ def test_attention_key_padding():
     kend = torch.tensor(valid, dtype=torch.int32, device=d)
     out = E.test_attention(q.to(d), k.to(d), v.to(d), kend=kend)
     assert rel_err(out, ref) <= TOL
+
+
+@pytest.mark.parametrize('epi', ['none', 'residual', 'swiglu'])
+def test_gemm_mixed_tile_heights_bitwise(epi):
+    """Prefill-sized M (8 x 739 rows), where the planner mixes 256-row and 128-row tiles in one launch: the automatic
+    choice, an explicit mix and both pure forms must agree bit for bit (same k order and MFMA per output element)."""
+    from oracle_amd import engine as E
+    M, K, N = 5912, 512, 4096
+    x = _rand((M, K), 21)
+    w = _rand((N, K), 22, 0.03)
+    res = _rand((M, N), 23) if epi == 'residual' else None
+    d = _dev()
+    outs = {k: E.test_gemm(x.to(d), w.to(d), None, None if res is None else res.to(d), epi, kernel=k).cpu()
+            for k in (None, 'dma256', 'dma128', 'mix16', 'mix7')}
+    y = F.linear(x, w)
+    ref = {'none': y, 'residual': (res + y) if res is not None else y, 'swiglu': F.silu(y[:, :N // 2]) * y[:, N // 2:]}[epi]
+    assert rel_err(outs[None], ref) <= TOL
+    for k, v in outs.items():
+        assert torch.equal(v, outs['dma256']), k
