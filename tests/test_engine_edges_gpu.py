@@ -95,3 +95,34 @@ def test_capacity_and_argument_errors(chain16):
         eng.pool_views(torch.zeros(5 * 3, 576, 1024, dtype=torch.bfloat16, device='cuda'), [5, 5, 5])   # 5 views > pooler's 2304 positions
     with pytest.raises(ValueError):
         eng.vision_encode(torch.zeros(1, 3, 336, 336, device='cuda'))                                    # fp32 images are refused
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2, 3])
+def test_random_ragged_batches_match_oracle(chain16, seed):
+    """Seeded random batch shapes (1..16 rows, 1 / 3 / 4 views, ragged text around the image placeholder, rows ending at
+    different steps): generate() must return exactly the CPU oracle's tokens, pad fill included."""
+    import random
+    from oracle import cpu_ref as cr
+    from oracle_amd.dims import TINY
+    from oracle_amd.synth import CHAIN_BASE, CHAIN_LEN, synth_images
+    st, eng, model = chain16
+    rng = random.Random(100 + seed)
+    b = rng.choice([1, 2, 3, 5, 8, 11, 16])
+    views = rng.choice([1, 3, 4])
+    e = CHAIN_BASE + CHAIN_LEN
+    rows = []
+    for i in range(b):
+        pre = [rng.randrange(3, 1000) for _ in range(rng.randint(0, 9))]
+        post = [rng.randrange(3, 1000) for _ in range(rng.randint(0, 6))]
+        rows.append([1] + pre + [-200] + post + [e - rng.randint(2, 30)])     # 2..30 chain tokens, then EOS
+    L = max(len(r) for r in rows)
+    ids = torch.tensor([[0] * (L - len(r)) + r for r in rows])
+    imgs = synth_images(b, views, TINY, seed=900 + seed)
+    mv = 'learned' if views > 1 else 'concat'
+    model.config.mv_type = mv
+    try:
+        out = model.generate(ids.cuda(), images=imgs.cuda(), do_sample=False, use_cache=True, max_new_tokens=40).cpu()
+    finally:
+        model.config.mv_type = 'learned'
+    ref = cr.greedy_generate(st, TINY, ids, imgs, mv_type=mv, max_new_tokens=40)
+    assert torch.equal(out, ref), (b, views)
