@@ -97,3 +97,27 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(l, name), name
     l.orc_abi_version.restype = ctypes.c_int
     assert l.orc_abi_version() == 1
+
+
+def test_product_fails_loudly_without_library_or_device(monkeypatch):
+    """No CPU fallback anywhere in the product: a missing shared library or a missing HIP device is an error that says so,
+    and nothing under oracle_amd/ imports the oracle."""
+    import torch
+    from oracle_amd import _lib
+    from oracle_amd.dims import TINY
+    from oracle_amd.engine import Engine
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', os.path.join(ROOT, 'oracle_amd', 'csrc', 'no_such_library.so'))
+    with pytest.raises(_lib.OracleHipError, match='no fallback'):
+        _lib.lib()
+    if not torch.cuda.is_available():
+        with pytest.raises(_lib.OracleHipError, match='no CPU fallback'):
+            Engine(TINY)
+        from oracle_amd.llava.model.builder import load_pretrained_model
+        with pytest.raises(_lib.OracleHipError):
+            load_pretrained_model('synthetic:tiny', None, 'synthetic:tiny')
+    for base, _, files in os.walk(os.path.join(ROOT, 'oracle_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(base, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle(\s|\.|$)', src, flags=re.MULTILINE), os.path.join(base, f)
