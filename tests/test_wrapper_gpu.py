@@ -54,3 +54,16 @@ def test_adaptability_cli_end_to_end(tmp_path, monkeypatch, capsys):
     first = cli.main(argv)
     second = cli.main(argv)
     assert first == second and 'drilling' in first and 'kuka' in first
+
+
+@pytest.mark.parametrize('config', ['oracle.json', 'oracle_mv_learned_symbolic.json', 'oracle_mv_learned_symbolic_visual.json',
+                                    'oracle_mv_learned_temporal_pred.json', 'oracle_temporal_pred.json'])
+def test_cli_every_shipped_config_runs_and_repeats(config, tmp_path, monkeypatch):
+    """Every configuration file the reference ships for inference, through the CLI on the native engine (single view, symbolic,
+    visual descriptors, online temporal memory with batch 1): predictions for every frame, identical on a second run."""
+    from oracle_amd.scene_graph_prediction import main as cli
+    monkeypatch.chdir(tmp_path)
+    argv = ['--config', config, '--model_path', 'synthetic:tiny:chain', '--limit_frames', '6']
+    first = cli.main(argv)
+    second = cli.main(argv)
+    assert len(first) == 6 and first == second
