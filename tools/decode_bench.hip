@@ -243,7 +243,7 @@ int main(int argc, char** argv) {
   // ---- one full layer sequence (7 launches), distinct weights per call
   {
     const size_t layer_bytes = ((size_t)4 * d * d + (size_t)3 * d * ff) * 2;
-    float us = time_it([&](int i) {
+    auto layer = [&](int i) {
       char* base = (char*)pool + ((size_t)(i % 6) * layer_bytes);
       GemvArgs a = {};
       a.bias = nullptr; a.M = M; a.H = H; a.kbeg = ints + 16; a.cur_len = ints; a.x_xf = 1; a.c_xf = 1;
@@ -268,7 +268,28 @@ int main(int argc, char** argv) {
       a.X = Y; a.ldx = ff; a.K = ff; a.Wp = (const bf16_t*)(base + ((size_t)4 * d * d + (size_t)2 * d * ff) * 2); a.C = X; a.R = X;
       a.ldr = d; a.ldc = d; a.N = d; a.Nvalid = d; a.ssq_out = ssq;
       CK(launch_gemv_ex(a, EPI_RESIDUAL, 0, s));
-    });
+    };
+    float us = time_it(layer);
+    if (getenv("GRAPH_EXP")) {
+      // the same 32-layer step as ONE hipGraph launch: does replaying pre-built packets shorten the gaps between kernels?
+      hipStream_t cs;
+      CK(hipStreamCreate(&cs));
+      hipStream_t saved = s;
+      s = cs;
+      hipGraph_t graph; hipGraphExec_t exec;
+      CK(hipStreamBeginCapture(cs, hipStreamCaptureModeGlobal));
+      for (int i = 0; i < 32; ++i) layer(i);
+      CK(hipStreamEndCapture(cs, &graph));
+      CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      for (int i = 0; i < 3; ++i) CK(hipGraphLaunch(exec, cs));
+      CK(hipEventRecord(e0, cs));
+      for (int i = 0; i < 20; ++i) CK(hipGraphLaunch(exec, cs));
+      CK(hipEventRecord(e1, cs));
+      CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("32-layer step as one hipGraph : %7.2f us per layer\n", ms * 1e3f / (20 * 32));
+      s = saved;
+    }
     const size_t bytes = layer_bytes + (size_t)M * H * ctx * 512;
     printf("full layer (7 launches)      : %7.2f us  %7.1f GB/s  -> %.2f ms / 32-layer step\n", us, bytes / us * 1e-3, us * 32e-3);
   }
