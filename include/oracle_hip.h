@@ -110,6 +110,11 @@ int orc_test_layernorm(const void* x, const void* w, const void* b, int rows, in
 int orc_test_attention(const void* q, const void* k, const void* v, int B, int H, int Sq, int Sk, int head_dim,
                        const int32_t* kbeg, const int32_t* kend, int causal, int q_off, float scale, void* out,
                        void* stream);
+/* decode attention over a KV cache, the engine's own launch (un-split for batch * heads >= 192, split + combine below):
+ * q (batch, heads*128); kcache / vcache (batch, heads, t_max, 128); kbeg device (batch) first valid key per row or NULL;
+ * keys [kbeg[b], n_keys) are attended (the decode-step branch of LlamaAttention under llava_llama.py:54-100). Synchronous. */
+int orc_test_decode_attention(const void* q, const void* kcache, const void* vcache, int batch, int heads, int t_max,
+                              const int32_t* kbeg, int n_keys, void* out, void* stream);
 /* HIP-event sampling of the dominant decode kernel (gate/up projection GEMV of every 8th layer): start / stop events
  * attached to the launch itself (the dispatch's timestamps) on the stream the kernel is launched on. enable(1) resets the samples; read() synchronises the device and returns
  * the summed duration, the number of sampled launches and the algorithmic bytes of one launch. */

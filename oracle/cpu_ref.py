@@ -324,7 +324,7 @@ def llama_forward(st, d, inputs_embeds, mask_full, position_ids, kv=None, all_lo
 # ----------------------------------------------------------------------------- greedy search (A9/A10)
 def greedy_generate(st, d, input_ids, images, mv_type='learned', max_new_tokens=300, vis_descriptor_embs=None,
                     pad_token_id=0, eos_token_id=2, padding_side='left', max_length=None,
-                    forced_tokens=None, return_trace=False, image_features=None):
+                    forced_tokens=None, return_trace=False, image_features=None, trace_logits_stride=None):
     """model.generate(..., do_sample=False, use_cache=True) as called at scene_graph_prediction_model_oracle.py:135-143.
 
     forced_tokens (B, n) teacher-forces the fed-back token (the argmax is still recorded) so that GPU and CPU
@@ -344,6 +344,8 @@ def greedy_generate(st, d, input_ids, images, mv_type='learned', max_new_tokens=
         if return_trace:
             top2 = torch.topk(logits, 2, dim=-1)
             trace.append({'argmax': nxt.clone(), 'top2_val': top2.values.clone(), 'top2_idx': top2.indices.clone()})
+            if trace_logits_stride:
+                trace[-1]['logits_sub'] = logits[:, ::trace_logits_stride].clone()
         nxt = nxt * unfinished + pad_token_id * (1 - unfinished)
         cur = torch.cat([cur, nxt[:, None]], dim=1)
         attn = torch.cat([attn, torch.ones(b, 1, dtype=torch.bool)], dim=1)

@@ -268,6 +268,66 @@ def gen_llm_wide():
     save('llm_wide_bfloat16', **out)
 
 
+def wide_batch_prompts(n_rows, seed):
+    """n_rows ragged left-padded rows at the plain-prompt scale (T between ~620 and ~740 after the 576 image rows)."""
+    g = torch.Generator().manual_seed(seed)
+    rows = []
+    for i in range(n_rows):
+        nb = int(torch.randint(8, 31, (1,), generator=g))
+        na = int(torch.randint(12, 131, (1,), generator=g)) if i else 130          # row 0 is the longest: no padding
+        a = torch.randint(3, 31999, (nb,), generator=g)
+        b = torch.randint(3, 31999, (na,), generator=g)
+        a[a == 18610] = 18611
+        b[b == 18610] = 18611
+        rows.append([1] + a.tolist() + [-200] + b.tolist())
+    L = max(len(r) for r in rows)
+    return torch.tensor([[0] * (L - len(r)) + r for r in rows])
+
+
+def gen_llm_wide_batch():
+    """The headline's decode code path under the reference: full-width LLaMA layers, 8 and 16 ragged left-padded rows
+    (un-split decode attention, B*H >= 192; persistent GEMVs with 8 / 16 live rows). Stored: prefill logits and the
+    logits of 8 greedy decode steps from the REAL reference's generate() in bf16 (output_scores), and the same steps
+    teacher-forced along those tokens in fp32 (the restatement, bit-identical to the reference in fp32) as the
+    'exact math' floor."""
+    dtype = torch.bfloat16
+    st = synth_state(WIDE2, seed=11, dtype=dtype)
+    n_new = 9
+    out = {}
+    model, cfg = rh.build_reference_model(WIDE2, st, dtype=dtype)
+    toks = {}
+    for tag, nrows, seed in (('b8', 8, 201), ('b16', 16, 202)):
+        ids = wide_batch_prompts(nrows, seed)
+        imgs = synth_images(nrows, 3, WIDE2, seed=600 + nrows).to(dtype)
+        with torch.inference_mode():
+            r = model.generate(ids, images=imgs, do_sample=False, use_cache=True, max_new_tokens=n_new,
+                               past_key_values=rh.legacy_cache(cfg), output_scores=True, return_dict_in_generate=True)
+        gen = r.sequences
+        scores = torch.stack([s.float() for s in r.scores], dim=1)             # (B, n_new, V): raw logits of every step
+        assert scores.shape[1] == n_new and torch.equal(scores.argmax(-1), gen[:, ids.shape[1]:])
+        top = torch.topk(scores[:, 0], 16, dim=-1)
+        out[f'{tag}.ids'] = ids.numpy()
+        out[f'{tag}.generated'] = gen.numpy()
+        out[f'{tag}.top16_val'] = top.values.numpy()
+        out[f'{tag}.top16_idx'] = top.indices.numpy()
+        out[f'{tag}.logits_sub'] = scores[:, :, ::97].numpy()
+        out[f'{tag}.logits_absmax'] = scores.abs().max(-1).values.numpy()
+        top2 = torch.topk(scores, 2, dim=-1).values
+        out[f'{tag}.margin'] = (top2[..., 0] - top2[..., 1]).numpy()
+        toks[tag] = (ids, imgs, gen)
+        mine = cr.greedy_generate(st, WIDE2, ids, imgs, max_new_tokens=n_new)
+        print(tag, 'T', ids.shape[1] - 1 + 576, 'restatement equal:', torch.equal(mine, gen))
+        assert torch.equal(mine, gen)
+    del model
+    st32 = {k: v.float() for k, v in st.items()}
+    for tag, (ids, imgs, gen) in toks.items():
+        new = gen[:, ids.shape[1]:]
+        _, trace = cr.greedy_generate(st32, WIDE2, ids, imgs.float(), max_new_tokens=n_new, forced_tokens=new,
+                                      return_trace=True, trace_logits_stride=97)
+        out[f'{tag}.logits_sub_fp32'] = torch.stack([t['logits_sub'] for t in trace], dim=1).numpy()
+    save('llm_wide_batch_bfloat16', **out)
+
+
 def chain_prompts():
     ends = [CHAIN_BASE + CHAIN_LEN - 9, CHAIN_BASE + CHAIN_LEN - 30, CHAIN_BASE + CHAIN_LEN - 17]
     rows = [[1, 5, 6, -200, 7, 8, 9, 10, ends[0]], [1, 21, -200, 22, ends[1]], [1, 31, 32, 33, 34, 35, -200, 36, 37, 38, 39, ends[2]]]
@@ -345,6 +405,7 @@ ALL = {
     'llm_f32': lambda: gen_llm('float32'),
     'llm_bf16': lambda: gen_llm('bfloat16'),
     'llm_wide': gen_llm_wide,
+    'llm_batchwide': gen_llm_wide_batch,
     'text': gen_text,
 }
 

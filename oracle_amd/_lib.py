@@ -47,6 +47,7 @@ SYMBOLS = {
     'orc_test_rmsnorm': (_I, [_P, _P, _I, _I, _F, _P, _P]),
     'orc_test_layernorm': (_I, [_P, _P, _P, _I, _I, _F, _P, _P]),
     'orc_test_attention': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _F, _P, _P]),
+    'orc_test_decode_attention': (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _P, _P]),
     'orc_profile_enable': (_I, [_P, _I]),
     'orc_profile_read': (_I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(_L)]),
     'orc_decode_weight_bytes': (_L, [_P]),

@@ -16,10 +16,11 @@ static thread_local char g_err[512] = "";
 extern "C" const char* orc_last_error(void) { return g_err; }
 extern "C" int orc_abi_version(void) { return 1; }
 
-static int fail(const char* what, const char* detail) {
+int orc_fail(const char* what, const char* detail) {
   snprintf(g_err, sizeof(g_err), "%s: %s", what, detail);
   return -1;
 }
+static int fail(const char* what, const char* detail) { return orc_fail(what, detail); }
 #define HIPCHK(expr)                                                   \
   do {                                                                 \
     hipError_t _e = (expr);                                            \
@@ -99,6 +100,7 @@ struct orc_engine {
   int *d_step, *d_curlen, *d_nunf, *d_unf, *d_next, *d_argmax, *d_kbeg, *d_kend, *d_rowoff, *d_rowvalid, *d_tokens;
   int* h_pinned = nullptr;   // pinned host staging (small int arrays)
   int cur_batch = 0, cur_T = 0;
+  int steps_issued = 0;   // decode steps enqueued since the last prefill (host-side mirror of the device cur_len - T)
   // sampled HIP-event timing of the dominant decode kernel (gate/up GEMV), see orc_profile_*
   bool prof_on = false;
   std::vector<hipEvent_t> ev_a, ev_b;
@@ -235,8 +237,9 @@ extern "C" int orc_engine_create(const orc_config* cfg, orc_engine** out) {
   if (c.clip_d % c.clip_heads || c.clip_d / c.clip_heads != 64) return fail("orc_engine_create", "CLIP head_dim must be 64");
   if (c.clip_d / c.pool_heads != 128) return fail("orc_engine_create", "pooler head_dim must be 128");
   if (c.max_batch < 1 || c.max_batch > 16) return fail("orc_engine_create", "max_batch must be in 1..16");
-  if (c.d_model % 128 || c.d_ff % 64 || c.vocab % 128 || c.clip_d % 128 || c.clip_ff % 128 || c.pool_ff % 128)
-    return fail("orc_engine_create", "widths must be multiples of 128 (d_ff: 64)");
+  if (c.d_model % 256 || c.d_ff % 64 || c.vocab % 128 || c.clip_d % 128 || c.clip_ff % 128 || c.pool_ff % 128)
+    return fail("orc_engine_create", "widths must be multiples of 128 (d_model: 256, i.e. an even head count; d_ff: 64)");
+  if (c.max_seq < 2 || c.max_new_tokens < 1 || c.max_images < 1) return fail("orc_engine_create", "capacities must be positive");
   if (c.clip_image % c.clip_patch) return fail("orc_engine_create", "image size not a multiple of the patch size");
   orc_engine* e = new orc_engine();
   e->c = c;
@@ -729,6 +732,7 @@ extern "C" int orc_prefill(orc_engine* e, const void* embeds, const int32_t* pos
   HIPCHK(hipMemcpyAsync(e->d_kbeg, hp + 16 + 48, 16 * 4, hipMemcpyHostToDevice, s));
   e->cur_batch = B;
   e->cur_T = T;
+  e->steps_issued = 0;
   const int d = c.d_model, M = B * T;
   HIPCHK(hipMemcpyAsync(e->w_h, embeds, (size_t)M * d * 2, hipMemcpyDeviceToDevice, s));
   ORCCHK(llama_prefill_layers(e, e->w_h, e->w_xn, e->w_qkv, e->w_att, e->w_mlp, B, T, position_ids, s));
@@ -737,9 +741,23 @@ extern "C" int orc_prefill(orc_engine* e, const void* embeds, const int32_t* pos
   return 0;
 }
 
+// decode step k (1-based since the prefill) writes K/V slot T + k - 1 of every row: refuse the step that would leave the
+// cache (the device counters are only mirrored here; nothing on the device bounds the slot)
+static int check_capacity(orc_engine* e, int n_steps, const char* who) {
+  if (n_steps < 0) return fail(who, "negative step count");
+  if (e->cur_T + e->steps_issued + n_steps > e->c.max_seq) {
+    char msg[160];
+    snprintf(msg, sizeof(msg), "KV cache full: prompt %d + %d steps taken + %d requested > max_seq %d", e->cur_T, e->steps_issued,
+             n_steps, e->c.max_seq);
+    return fail(who, msg);
+  }
+  return 0;
+}
+
 static int decode_one(orc_engine* e, const int32_t* forced, float* logits_out, hipStream_t s) {
   const orc_config& c = e->c;
   const int B = e->cur_batch;
+  ++e->steps_issued;
   HIPCHK(launch_embed_tokens(forced ? forced : e->d_next, e->embed, e->d_h, B, c.d_model, c.vocab, e->d_ssq, c.d_model / 16, s));
   ORCCHK(llama_decode_layers(e, B, s));
   ORCCHK(head_and_sample(e, e->d_h, c.d_model, B, logits_out, true, s));
@@ -748,11 +766,13 @@ static int decode_one(orc_engine* e, const int32_t* forced, float* logits_out, h
 
 extern "C" int orc_decode_step(orc_engine* e, const int32_t* forced_ids, float* logits_out, void* stream) {
   if (!e || !e->finalized || e->cur_batch == 0) return fail("orc_decode_step", "no prefill has run");
+  ORCCHK(check_capacity(e, 1, "orc_decode_step"));
   return decode_one(e, forced_ids, logits_out, S(stream));
 }
 
 extern "C" int orc_decode_steps(orc_engine* e, int n_steps, void* stream) {
   if (!e || !e->finalized || e->cur_batch == 0) return fail("orc_decode_steps", "no prefill has run");
+  ORCCHK(check_capacity(e, n_steps, "orc_decode_steps"));
   for (int i = 0; i < n_steps; ++i) ORCCHK(decode_one(e, nullptr, nullptr, S(stream)));
   return 0;
 }
@@ -867,5 +887,34 @@ extern "C" int orc_test_attention(const void* q, const void* k, const void* v, i
   a.O = (bf16_t*)out; a.o_bs = a.q_bs; a.o_hs = a.q_hs; a.o_ts = hd;
   a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.kbeg = kbeg; a.kend = kend; a.causal = causal; a.q_off = q_off; a.scale = scale;
   HIPCHK(launch_attention(a, hd, S(stream)));
+  return 0;
+}
+
+// q (B, H*128); kcache / vcache (B, H, Tmax, 128); kbeg device (B) or null; keys [kbeg[b], n_keys) are attended.
+// Runs the engine's own launch (launch_decode_attention: un-split for B*H >= 192, split + combine below). Synchronous.
+extern "C" int orc_test_decode_attention(const void* q, const void* kcache, const void* vcache, int B, int H, int Tmax,
+                                         const int32_t* kbeg, int n_keys, void* out, void* stream) {
+  if (!q || !kcache || !vcache || !out) return fail("orc_test_decode_attention", "null argument");
+  if (B < 1 || B > 16 || H < 1 || Tmax < 1 || n_keys < 1 || n_keys > Tmax) return fail("orc_test_decode_attention", "bad size");
+  hipStream_t s = S(stream);
+  float* part = nullptr;
+  int* ints = nullptr;
+  HIPCHK(hipMalloc((void**)&part, (size_t)B * H * DECODE_NSPLIT * 130 * 4));
+  HIPCHK(hipMalloc((void**)&ints, 32 * 4));
+  int host[32] = {0};
+  host[0] = n_keys;
+  HIPCHK(hipMemcpyAsync(ints, host, sizeof(host), hipMemcpyHostToDevice, s));
+  if (kbeg) HIPCHK(hipMemcpyAsync(ints + 16, kbeg, B * 4, hipMemcpyDeviceToDevice, s));
+  DecodeAttnArgs a;
+  a.o_xf = 0;
+  a.Q = (const bf16_t*)q; a.q_bs = (long)H * 128; a.Kc = (const bf16_t*)kcache; a.Vc = (const bf16_t*)vcache;
+  a.c_hs = (long)Tmax * 128; a.c_bs = a.c_hs * H; a.O = (bf16_t*)out; a.o_bs = (long)H * 128;
+  a.part = part; a.kbeg = ints + 16; a.cur_len = ints; a.B = B; a.H = H; a.scale = 0.08838834764831845f;
+  hipError_t err = launch_decode_attention(a, s);
+  hipError_t err2 = hipStreamSynchronize(s);
+  (void)hipFree(part);
+  (void)hipFree(ints);
+  if (err != hipSuccess) return fail("orc_test_decode_attention", hipGetErrorString(err));
+  if (err2 != hipSuccess) return fail("orc_test_decode_attention", hipGetErrorString(err2));
   return 0;
 }

@@ -5,6 +5,9 @@
 
 #include "common.h"
 
+// records "what: detail" for orc_last_error() and returns -1 (engine.hip)
+int orc_fail(const char* what, const char* detail);
+
 enum { EPI_NONE = 0, EPI_QUICKGELU = 1, EPI_GELU = 2, EPI_RESIDUAL = 3, EPI_SWIGLU = 4, EPI_F32 = 5, EPI_ROPE_KV = 6 };
 
 struct GemmArgs {

@@ -224,3 +224,13 @@ def test_attention(q, k, v, kbeg=None, kend=None, causal=False, q_off=0, scale=N
     _lib.check(_lib.lib().orc_test_attention(_ptr(q), _ptr(k), _ptr(v), b, h, sq, sk, hd, _ptr(kbeg), _ptr(kend),
                                              1 if causal else 0, q_off, scale, _ptr(out), _stream()), 'attention')
     return out
+
+
+def test_decode_attention(q, kcache, vcache, n_keys, kbeg=None):
+    """q (B, H*128), kcache / vcache (B, H, Tmax, 128) contiguous bf16; kbeg int32 device (B,) or None -> (B, H*128)."""
+    b, h, tmax, hd = kcache.shape
+    assert hd == 128 and q.shape == (b, h * 128)
+    out = torch.empty_like(q)
+    _lib.check(_lib.lib().orc_test_decode_attention(_ptr(q), _ptr(kcache), _ptr(vcache), b, h, tmax, _ptr(kbeg), int(n_keys),
+                                                    _ptr(out), _stream()), 'decode_attention')
+    return out

@@ -4,6 +4,7 @@ greedy `generate()` the ORacle wrapper calls (scene_graph_prediction_model_oracl
 the KV cache, KV-cached decode and greedy sampling all run inside the native engine; this file reproduces
 transformers' greedy-search bookkeeping around it."""
 import types
+import warnings
 
 import torch
 
@@ -171,8 +172,14 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
             embeds = self.get_model().embed_tokens(input_ids)
             mask, pos = attention_mask, inp['position_ids']
         t = embeds.shape[1]
+        if t >= self.engine.max_seq:
+            raise ValueError(f'prompt ({t}) exceeds the KV capacity {self.engine.max_seq}')
         if t + max_new_tokens > self.engine.max_seq:
-            raise ValueError(f'prompt ({t}) + max_new_tokens ({max_new_tokens}) exceeds the KV capacity {self.engine.max_seq}')
+            # the engine's KV cache plays the part of transformers' max_length: generation stops at the capacity
+            # (the reference would run on to the model's 4096 positions; size max_seq for that, see builder.py)
+            warnings.warn(f'prompt ({t}) + max_new_tokens ({max_new_tokens}) exceeds the KV capacity {self.engine.max_seq}: '
+                          f'generating at most {self.engine.max_seq - t} tokens')
+            max_new_tokens = self.engine.max_seq - t
         self.engine.prefill(embeds.to(torch.bfloat16).contiguous(), pos.to(device=self.device, dtype=torch.int32).contiguous(),
                             self._left_pad(mask))
         while True:

@@ -78,8 +78,26 @@ def test_capacity_and_argument_errors(chain16):
     imgs = synth_images(2, 3, TINY, seed=5).cuda()
     with pytest.raises(ValueError, match='max_new_tokens'):
         model.generate(ids.cuda(), images=imgs, max_new_tokens=49)
+    from oracle_amd.synth import CHAIN_BASE, CHAIN_LEN
+    ends = torch.tensor([[CHAIN_BASE + CHAIN_LEN - 30], [CHAIN_BASE + CHAIN_LEN - 35]])        # >= 30 tokens before EOS
+    long_ids = torch.cat([ids[:, :-1], ids.new_full((2, 100), 5), ends], 1)                    # T = 681 of 700 slots
+    with pytest.warns(UserWarning, match='KV capacity'):
+        out = model.generate(long_ids.cuda(), images=imgs, max_new_tokens=40)
+    assert out.shape[1] - long_ids.shape[1] == 700 - (long_ids.shape[1] - 1 + 576)             # clamped to the free slots
     with pytest.raises(ValueError, match='KV capacity'):
-        model.generate(torch.cat([ids, ids.new_full((2, 120), 5)], 1).cuda(), images=imgs, max_new_tokens=40)
+        model.generate(torch.cat([ids, ids.new_full((2, 130), 5)], 1).cuda(), images=imgs, max_new_tokens=4)
+    # the C ABI itself refuses a decode step that would write past the cache (K/V slot = cur_len - 1 was unchecked)
+    t = long_ids.shape[1] - 1 + 576
+    o = model(input_ids=long_ids.cuda(), attention_mask=(long_ids != 0).cuda(), images=imgs)
+    eng.decode_steps(700 - t - 2)
+    eng.decode_step(torch.tensor([5, 5]).cuda())
+    eng.decode_step(torch.tensor([5, 5]).cuda())                                               # slot 699: the last one
+    with pytest.raises(_lib.OracleHipError, match='KV cache full'):
+        eng.decode_step(torch.tensor([5, 5]).cuda())
+    with pytest.raises(_lib.OracleHipError, match='KV cache full'):
+        eng.decode_steps(1)
+    with pytest.raises(_lib.OracleHipError, match='KV cache full'):
+        model(input_ids=torch.tensor([[5], [5]]).cuda(), past_key_values=o.past_key_values)
     with pytest.raises(NotImplementedError):
         model.generate(ids.cuda(), images=imgs, do_sample=True)
     right_padded = torch.tensor([[1, 5, -200, 6, 0, 0], [1, 5, -200, 6, 7, 8]])

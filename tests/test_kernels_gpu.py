@@ -179,3 +179,60 @@ def test_gemm_mixed_tile_heights_bitwise(epi):
     assert rel_err(outs[None], ref) <= TOL
     for k, v in outs.items():
         assert torch.equal(v, outs['dma256']), k
+
+
+@pytest.mark.parametrize('B,H', [(2, 32), (6, 32), (8, 32), (16, 32), (16, 12), (1, 32), (3, 4)])
+def test_decode_attention_split_and_unsplit_branches(B, H):
+    """Decode attention over the KV cache through the engine's own launch: B*H in {64, 192, 256, 512, ...} covers the
+    split + combine path (B*H < 192) and the un-split single-workgroup path the batch-8 headline runs (8 x 32 = 256),
+    with ragged left padding. Reference = the eager formula of LlamaAttention for one query token (scores rounded to
+    bf16 after the product and after the scale, fp32 softmax, bf16 probabilities)."""
+    from oracle_amd import engine as E
+    tmax, n_keys = 800, 777
+    q = _rand((B, H * 128), 30 + B)
+    kc, vc = _rand((B, H, tmax, 128), 31 + B), _rand((B, H, tmax, 128), 32 + B)
+    pad = [(37 * b * b) % 700 for b in range(B)]
+    if B > 1:
+        pad[-1] = n_keys - 1                                            # a row with a single visible key
+    dt = torch.bfloat16
+    add = torch.zeros(B, 1, 1, n_keys, dtype=dt)
+    for b in range(B):
+        add[b, 0, 0, :pad[b]] = torch.finfo(dt).min
+    ref = _eager(q.view(B, H, 1, 128), kc[:, :, :n_keys], vc[:, :, :n_keys], add, 128 ** -0.5).reshape(B, H * 128)
+    d = _dev()
+    kbeg = torch.tensor(pad, dtype=torch.int32, device=d)
+    out = E.test_decode_attention(q.to(d), kc.to(d), vc.to(d), n_keys, kbeg).cpu()
+    assert torch.isfinite(out.float()).all()
+    assert rel_err(out, ref) <= TOL, (B, H, rel_err(out, ref))
+    for b in range(B):                                                  # per row, so a wrong row cannot hide behind a large one
+        assert rel_err(out[b], ref[b]) <= TOL, (b, pad[b])
+    if B > 1:                                                           # one visible key: the output IS that value row
+        assert torch.equal(out[-1].view(H, 128), vc[-1, :, n_keys - 1])
+
+
+@pytest.mark.parametrize('M', [1, 8, 16])
+@pytest.mark.parametrize('epi,N,K', [('swiglu', 22016, 4096), ('f32', 32000, 4096), ('residual', 4096, 11008), ('none', 12288, 4096)])
+def test_decode_gemv_at_llama7b_shapes(epi, N, K, M):
+    """The decode GEMVs at the real LLaMA-7B shapes and 1 / 8 / 16 live rows: gate/up (688 units) and lm_head (1000 units)
+    take the PERSISTENT kernels the headline bench runs (gemv_pers_kernel<2,SWIGLU,12,1>, <2,F32,8,1>), down the 16-wave
+    one-unit kernel, 12288 x 4096 the 384-unit shape of the fused q/k/v projection. Also pins batch invariance: row 0 of
+    the M-row launch is bit-identical to the same row launched alone (the K split depends on the shape only)."""
+    from oracle_amd import engine as E
+    x = _rand((M, K), 41)
+    w = _rand((N, K), 42, 0.02)
+    res = _rand((M, N), 43) if epi == 'residual' else None
+    y = F.linear(x, w)
+    if epi == 'swiglu':
+        ref = F.silu(y[:, :N // 2]) * y[:, N // 2:]
+    elif epi == 'residual':
+        ref = res + y
+    elif epi == 'f32':
+        ref = F.linear(x.float(), w.float())
+    else:
+        ref = y
+    d = _dev()
+    out = E.test_gemm(x.to(d), w.to(d), None, None if res is None else res.to(d), epi, use_gemv=True).cpu()
+    assert rel_err(out, ref) <= TOL, rel_err(out, ref)
+    if M > 1:
+        one = E.test_gemm(x[:1].to(d), w.to(d), None, None if res is None else res[:1].to(d), epi, use_gemv=True).cpu()
+        assert torch.equal(one[0], out[0])
