@@ -22,6 +22,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (MI355X_MICROARCH.md; never the 2:1-sparsity figure)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
@@ -117,6 +118,85 @@ def pmc_traffic():
     return None, None
 
 
+def stage_flops(batch, views, T, mv_type):
+    """Algorithmic FLOPs of the MFMA-bound stages of one step (SURVEY.md 8d formulas, full 7B dims)."""
+    S = 576 * views
+    vision = batch * views * 366.0e9 + batch * 24.16e9 * (views if mv_type == 'concat' else 1)
+    if mv_type == 'learned':
+        vision += batch * 2 * (25165824.0 * S + 4096.0 * S * S)
+    prefill = batch * (2 * 6476267520.0 * T + 131072.0 * T * T + 262144000.0)
+    return vision, prefill
+
+
+def self_check(model, eng, input_ids, images, new, n=32, tol=2e-2):
+    """Full-size property check after the timed region: row 0 decoded ALONE (batch 1: split decode attention + combine)
+    against row 0 of the timed batch (batch 8: un-split decode attention, persistent GEMVs with 8 live rows). The GEMVs
+    are bit-invariant to the batch; the two attention paths differ in fp32 summation order only, so the tokens are
+    expected to be identical; where one differs, the batch's token must still be within `tol` x max|logit| of the batch-1
+    argmax (the margin rule of the parity tests). Returns a small report; 'ok' iff every step passes."""
+    import torch
+    n = min(n, new.shape[1])
+    L = input_ids.shape[1]
+    one = model.generate(input_ids[:1], images=images[:1], do_sample=False, use_cache=True, max_new_tokens=n, chunk=n)[0, L:L + n]
+    ref = new[0, :n].to(one.device)
+    identical = int((one == ref).long().cumprod(0).sum())
+    mask = torch.ones_like(input_ids[:1], dtype=torch.bool)
+    logits = model(input_ids=input_ids[:1], attention_mask=mask, images=images[:1], use_cache=True).logits[:, -1].float()
+    worst = 0.0
+    ok = True
+    for s in range(n):
+        gap = float(logits.max() - logits[0, ref[s]]) / float(logits.abs().max())
+        worst = max(worst, gap)
+        ok = ok and gap <= tol
+        if s + 1 < n:
+            logits = eng.decode_step(ref[s:s + 1], want_logits=True).float()
+    return {'result': 'ok' if ok else 'FAILED', 'row0_tokens_identical_prefix': identical, 'steps': n,
+            'worst_gap_to_batch1_argmax_rel': worst, 'tol': tol}
+
+
+def launch_ranks(n):
+    """`bench.py --gpus N` without an external launcher: this parent process never touches a GPU (no torch import); it
+    starts N fresh ranks through torch.distributed.run on the loopback address and passes rank 0's JSON line through."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def dry_run(a):
+    """The multi-rank skeleton of main() with a stand-in step (no engine, no GPU): rendezvous over gloo, barrier, K timed
+    steps with the per-step all-gather of (batch, new_tokens) int32 ids, max over ranks; rank 0 prints the JSON line."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+    if world > 1:
+        dist.init_process_group('gloo')
+    new = torch.full((a.batch, a.new_tokens), rank, dtype=torch.int32)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        time.sleep(0.01 * (rank + 1))
+        if world > 1:
+            parts = [torch.empty_like(new) for _ in range(world)]
+            dist.all_gather(parts, new)
+            assert [int(p[0, 0]) for p in parts] == list(range(world))
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({'dry_run': True, 'n_gpus': world, 'steps': a.steps, 'frames': world * a.steps * a.batch,
+                          'ms_per_step': float(t) / a.steps * 1e3, 'slowest_rank_floor_ms': 10.0 * world}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -128,7 +208,19 @@ def main():
     ap.add_argument('--prompt', default='plain', choices=['plain', 'symbolic', 'temporal'])
     ap.add_argument('--dims', default='full', choices=['full', 'tiny'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-self-check', action='store_true')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='launcher / rendezvous / gather / max-over-ranks plumbing only (no GPU, no engine): CPU test of the N>1 path')
     a = ap.parse_args()
+    if a.gpus < 1:
+        ap.error('--gpus must be >= 1')
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(a.gpus))
+    if int(os.environ.get('WORLD_SIZE', 1)) != a.gpus:
+        sys.exit(f'bench.py: --gpus {a.gpus} does not match WORLD_SIZE={os.environ.get("WORLD_SIZE")} of the launcher')
+
+    if a.dry_run:
+        return dry_run(a)
 
     import torch
     import torch.distributed as dist
@@ -223,6 +315,10 @@ def main():
     torch.cuda.synchronize()
     t_dec = time.perf_counter() - s0
 
+    check = None
+    if rank == 0 and a.batch > 1 and not a.no_self_check:
+        check = self_check(model, eng, input_ids, images, new)
+
     if rank == 0:
         frames = world * a.steps * a.batch
         lat.sort()
@@ -232,6 +328,7 @@ def main():
         ctx = T + a.new_tokens / 2
         dec_bytes = eng.decode_weight_bytes() + eng.kv_bytes_per_key() * ctx * a.batch
         traffic, traffic_src = pmc_traffic()
+        fl_vis, fl_pre = stage_flops(a.batch, a.views, T, cfg.mv_type)
         res = {
             'metric': 'scene graphs (frames)/sec whole node, 3-view LLaVA-7B bf16; p50 frame latency',
             'value': frames / elapsed, 'unit': 'frames/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
@@ -241,9 +338,13 @@ def main():
                                    f'{a.prompt} ORacle prompt (spliced T={T}), greedy decode {a.new_tokens} new tokens/frame (length stop; '
                                    f'random-init weights), full generate() incl. CLIP x{a.views * a.batch}, pooler, projector, splice, 32-layer prefill',
                        'dims': a.dims, 'batch': a.batch, 'views': a.views, 'new_tokens': a.new_tokens, 'prompt_tokens_spliced': T,
-                       'parallelism': f'dp{world} (frame sharding, RCCL all-gather of token ids)'},
+                       'parallelism': f'dp{world} (frame sharding, RCCL all-gather of token ids)',
+                       'world_size': world, 'backend': backend if world > 1 else None, 'device': str(dev)},
             'p50_frame_latency_ms': lat[len(lat) // 2] * 1e3,
             'stage_ms': {'vision_fuse_splice': t_vis * 1e3, 'prefill': t_pre * 1e3, 'decode_total': t_dec * 1e3, 'decode_per_token': dec_ms},
+            'stage_roofline': None if a.dims != 'full' else {'bound': 'mfma', 'peak_TFLOPs': MFMA_PEAK_TFLOPS,
+                               'vision': {'flops': fl_vis, 'achieved_TFLOPs': fl_vis / t_vis / 1e12, 'frac': fl_vis / t_vis / 1e12 / MFMA_PEAK_TFLOPS},
+                               'prefill': {'flops': fl_pre, 'achieved_TFLOPs': fl_pre / t_pre / 1e12, 'frac': fl_pre / t_pre / 1e12 / MFMA_PEAK_TFLOPS}},
             'decode_step': {'algorithmic_bytes': dec_bytes, 'achieved_GBps': dec_bytes / (dec_ms * 1e-3) / 1e9,
                             'frac_of_hbm_peak': dec_bytes / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
             'roofline': {'kernel': 'gemv_pers_kernel<2,SWIGLU,12,1> (decode gate/up projection, 22016x4096 bf16 weights)', 'bound': 'hbm',
@@ -251,6 +352,9 @@ def main():
                          'traffic': traffic, 'traffic_source': traffic_src, 'launches_timed': prof_n, 'avg_launch_us': avg_us,
                          'algorithmic_bytes_per_launch': prof_bytes},
         }
+        if check is not None:
+            res['self_check'] = check['result']
+            res['self_check_detail'] = check
         if world == 1 and not a.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(a.new_tokens, a.views, T)
         print(json.dumps(res), flush=True)

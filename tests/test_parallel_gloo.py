@@ -71,3 +71,26 @@ def test_shard_properties():
     parts = [shard_indices(1378, r, 8, groups=groups) for r in range(8)]
     assert sorted(sum(parts, [])) == list(range(1378))
     assert sum(1 for p in parts if p) == 2               # parallelism is bounded by the number of takes
+
+
+def test_bench_launches_its_own_ranks_and_checks_world_size():
+    """`bench.py --gpus N` starts N ranks itself (no external torchrun), max-over-ranks timing and the per-step
+    all-gather run over gloo on the CPU (--dry-run: the engine step is a stand-in); --gpus != WORLD_SIZE is refused."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--dry-run'],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['frames'] == 2 * 3 * 8
+    assert res['ms_per_step'] >= res['slowest_rank_floor_ms']          # the slowest rank (rank 1 sleeps 20 ms) sets the time
+    env2 = dict(env, WORLD_SIZE='4', RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--dry-run'], capture_output=True, text=True,
+                       timeout=60, env=env2)
+    assert r.returncode != 0 and 'does not match WORLD_SIZE' in r.stderr
