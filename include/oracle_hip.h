@@ -80,6 +80,18 @@ int orc_preprocess_images(const uint8_t* rgb_hwc, int n_images, int height, int 
                           const int32_t* bounds, const int32_t* coeffs, int ksize, const void* lut_bf16,
                           const int32_t* fill_rgb_host, void* tmp, void* out_pixel_values, void* stream);
 
+/* No counterpart in the reference: orc_preprocess_images for callers that cannot allocate or bring a workspace (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc). Same arguments without `tmp`; the image between
+ * the two resample passes lives in a static per-GPU device buffer of orc_preprocess_noalloc_capacity() bytes (16 MiB, held
+ * until the process ends), so n_images * max(height, width) * out_size * 3 must not exceed it (error otherwise). Calls no
+ * hipMalloc / hipFree. The first call on a device resolves that device's buffer address (a call with n_images == 0 does
+ * only that: make it once outside graph capture). All calls on one GPU share the buffer: calls that overlap on one GPU
+ * (different streams or threads) race. */
+int orc_preprocess_images_noalloc(const uint8_t* rgb_hwc, int n_images, int height, int width, int out_size,
+                                  const int32_t* bounds, const int32_t* coeffs, int ksize, const void* lut_bf16,
+                                  const int32_t* fill_rgb_host, void* out_pixel_values, void* stream);
+int64_t orc_preprocess_noalloc_capacity(void);
+
 /* prepare_inputs_labels_for_multimodal, step 0 (reference llava_arch.py:245-359): gather the spliced
  * (rows, d_model) embedding matrix. codes[r] = kind<<28 | index; kind 0 = zero (padding) row,
  * 1 = embed_tokens[index], 2 = image_features[index], 3 = descriptors[index]. */

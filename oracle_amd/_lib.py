@@ -38,6 +38,8 @@ SYMBOLS = {
     'orc_view_reduce': (_I, [_P, _P, _I, _I, _L, _I, _P, _P]),
     'orc_pool2x2': (_I, [_P, _P, _I, _I, _I, _P, _P]),
     'orc_preprocess_images': (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _P, C.POINTER(C.c_int32), _P, _P, _P]),
+    'orc_preprocess_images_noalloc': (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _P, C.POINTER(C.c_int32), _P, _P]),
+    'orc_preprocess_noalloc_capacity': (_L, []),
     'orc_splice': (_I, [_P, _P, _I, _P, _P, _P, _P]),
     'orc_prefill': (_I, [_P, _P, _P, C.POINTER(C.c_int32), _I, _I, _P, _P]),
     'orc_decode_step': (_I, [_P, _P, _P, _P]),

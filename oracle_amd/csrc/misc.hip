@@ -1,8 +1,19 @@
 // Memory-bound glue kernels of the path: rotary + KV-cache write, patch extraction (patch-embed as GEMM),
 // embedding assembly for CLIP / pooler, the image-token splice gather, multi-view reductions, and the
 // greedy-search sampling state machine (argmax with lowest-index tie-break, EOS / pad bookkeeping).
+#include <stdio.h>
+
+#include <mutex>
+
+#include "../../include/oracle_hip.h"
 #include "common.h"
 #include "kernels.h"
+
+// Scratch of orc_preprocess_images_noalloc (the uint8 image between the two resample passes): ONE array per GPU, held
+// until the process ends. In host code this name is only a stand-in for the symbol: the per-device address comes from
+// hipGetSymbolAddress (scratch_for_current_device) and only that pointer is ever handed to a kernel.
+#define ORC_PREPROCESS_SCRATCH_BYTES (16u << 20)
+static __device__ __align__(256) uint8_t scratch[ORC_PREPROCESS_SCRATCH_BYTES];
 
 namespace {
 
@@ -380,4 +391,53 @@ hipError_t launch_argmax_sample(const SampleArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(argmax_sample_kernel, dim3(a.B), dim3(1024), 0, s, a);
   hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, s, a);
   return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ allocation-free preprocessing entry point
+namespace {
+constexpr int kMaxDevices = 64;
+uint8_t* g_scratch_ptr[kMaxDevices];   // device address of `scratch` on each GPU, resolved once per device
+std::mutex g_scratch_mu;
+
+// the current device's copy of `scratch` (each GPU holds its own array at its own address)
+int scratch_for_current_device(uint8_t** out) {
+  int dev = -1;
+  hipError_t err = hipGetDevice(&dev);
+  if (err != hipSuccess) return orc_fail("hipGetDevice", hipGetErrorString(err));
+  if (dev < 0 || dev >= kMaxDevices) return orc_fail("orc_preprocess_images_noalloc", "device index out of range");
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    err = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (err != hipSuccess || !p) return orc_fail("hipGetSymbolAddress(scratch)", hipGetErrorString(err));
+    g_scratch_ptr[dev] = (uint8_t*)p;
+  }
+  *out = g_scratch_ptr[dev];
+  return 0;
+}
+}  // namespace
+
+extern "C" int64_t orc_preprocess_noalloc_capacity(void) { return (int64_t)ORC_PREPROCESS_SCRATCH_BYTES; }
+
+extern "C" int orc_preprocess_images_noalloc(const uint8_t* rgb_hwc, int n_images, int height, int width, int out_size,
+                                             const int32_t* bounds, const int32_t* coeffs, int ksize, const void* lut_bf16,
+                                             const int32_t* fill_rgb_host, void* out, void* stream) {
+  uint8_t* tmp = nullptr;
+  if (int rc = scratch_for_current_device(&tmp)) return rc;
+  if (n_images == 0) return 0;   // set-up call: resolves this device's scratch address (do it once outside graph capture)
+  if (!rgb_hwc || !bounds || !coeffs || !lut_bf16 || !fill_rgb_host || !out) return orc_fail("orc_preprocess_images_noalloc", "null argument");
+  if (n_images < 0 || height < 1 || width < 1 || out_size < 1 || ksize < 1) return orc_fail("orc_preprocess_images_noalloc", "bad size");
+  const int64_t side = height > width ? height : width;
+  const int64_t need = (int64_t)n_images * side * out_size * 3;
+  if (need > (int64_t)ORC_PREPROCESS_SCRATCH_BYTES) {
+    char msg[200];
+    snprintf(msg, sizeof(msg), "needs %lld bytes of scratch (n_images * max(height, width) * out_size * 3), the static buffer holds %u",
+             (long long)need, ORC_PREPROCESS_SCRATCH_BYTES);
+    return orc_fail("orc_preprocess_images_noalloc", msg);
+  }
+  // pass 1 writes every byte of tmp[0, need) before pass 2 reads it (same stream): nothing of an earlier call is read
+  hipError_t err = launch_preprocess(rgb_hwc, n_images, height, width, out_size, bounds, coeffs, ksize, (const bf16_t*)lut_bf16,
+                                     fill_rgb_host[0], fill_rgb_host[1], fill_rgb_host[2], tmp, (bf16_t*)out, (hipStream_t)stream);
+  if (err != hipSuccess) return orc_fail("orc_preprocess_images_noalloc", hipGetErrorString(err));
+  return 0;
 }
