@@ -12,8 +12,8 @@ def init_from_env(backend=None):
     world = int(os.environ.get('WORLD_SIZE', 1))
     rank = int(os.environ.get('RANK', 0))
     if world > 1 and not dist.is_initialized():
-        if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend is None:   # ORC_DIST_BACKEND=gloo: rehearsal with several ranks sharing one GPU (RCCL wants one GPU per rank)
+            backend = os.environ.get('ORC_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
             torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
         dist.init_process_group(backend)

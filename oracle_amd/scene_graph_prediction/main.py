@@ -65,8 +65,14 @@ def main(argv=None):
                           relationNames=train_dataset.relationNames, model_path=args.model_path, mv_desc=mv_desc)
     takes = [int(s.split('_')[0]) for s in eval_dataset.scans]
     mine = parallel.shard_indices(len(eval_dataset), rank, world, groups=takes if temporal else None)
-    results = model.validate(batches(eval_dataset, batch_size, mine), return_raw_predictions=True)
+    results = model.validate(batches(eval_dataset, batch_size, mine), return_raw_predictions=True, report=world == 1)
     results = parallel.gather_objects(results, rank, world)
+    if world > 1:
+        # every rank saw only its shard: merge the per-frame labels and print the reference's reports ONCE, on rank 0,
+        # over the whole split (N partial reports are not the metric the reference prints)
+        frame_rel = parallel.gather_objects(model.last_frame_rel, rank, world)
+        if rank == 0:
+            model.report_merged(frame_rel, eval_dataset.scans)
     if args.mode == 'infer' and rank == 0:
         out = f'scan_relations_{name}_{split}.json'
         with open(out, 'w') as f:

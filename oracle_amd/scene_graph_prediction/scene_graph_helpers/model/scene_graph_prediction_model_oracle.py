@@ -209,8 +209,12 @@ class OracleWrapper:
             resolved.append((sub, pred, obj))
         return raw, resolved, humans
 
-    def validate(self, dataloader, limit_val_batches=None, logging_information=None, return_raw_predictions=False):
+    def validate(self, dataloader, limit_val_batches=None, logging_information=None, return_raw_predictions=False, report=True):
+        """report=False (multi-rank runs, oracle_amd/parallel.py): skip the per-shard classification reports; the caller
+        merges `last_frame_rel` of all ranks and calls `report_merged` once, so the printed per-take and overall reports
+        and the macro-F1 are those of the whole split, as the reference's single process prints them."""
         take_rel_preds, take_rel_gts = defaultdict(list), defaultdict(list)
+        frame_rel = {}
         scan_id_to_raw_predictions = {}
         limit = None
         if isinstance(limit_val_batches, int):
@@ -247,6 +251,7 @@ class OracleWrapper:
                 rel_preds = [(hmap.get(s, s), r, hmap.get(o, o)) for s, r, o in rel_preds]
                 labels = rel_labels.tolist()
                 gt_objects = sorted({x for s, _, o in labels for x in (s, o)}) if labels else []
+                n0 = len(take_rel_gts[take_idx])
                 for a in gt_objects:
                     for b in gt_objects:
                         if a == b:
@@ -262,12 +267,30 @@ class OracleWrapper:
                                 take_rel_preds[take_idx].append(self.relation_names_lower_case.index(map_vocab_idx_to_scene_graph_name(pr)))
                             except Exception:   # a nonsense relation counts as 'none'
                                 take_rel_preds[take_idx].append(none_id)
+                frame_rel[elem['scan_id']] = (take_idx, take_rel_preds[take_idx][n0:], take_rel_gts[take_idx][n0:])
+        self.last_frame_rel = frame_rel
         self.val_take_rel_preds, self.val_take_rel_gts = take_rel_preds, take_rel_gts
-        self.last_macro_f1 = self.evaluate_predictions(None, 'val', logging_information=logging_information)
         self.last_take_rel = (dict(take_rel_preds), dict(take_rel_gts))
+        if report:
+            self.last_macro_f1 = self.evaluate_predictions(None, 'val', logging_information=logging_information)
         self.reset_metrics(split='val')
         if return_raw_predictions:
             return scan_id_to_raw_predictions
+
+    def report_merged(self, frame_rel, scan_order, logging_information=None):
+        """Per-take and overall reports over per-frame labels gathered from all ranks ({scan_id: (take, preds, gts)}),
+        concatenated in dataset order (what one process iterating the whole split accumulates)."""
+        preds, gts = defaultdict(list), defaultdict(list)
+        for scan_id in scan_order:
+            if scan_id in frame_rel:
+                take_idx, p, g = frame_rel[scan_id]
+                preds[take_idx].extend(p)
+                gts[take_idx].extend(g)
+        self.val_take_rel_preds, self.val_take_rel_gts = preds, gts
+        self.last_take_rel = (dict(preds), dict(gts))
+        self.last_macro_f1 = self.evaluate_predictions(None, 'val', logging_information=logging_information)
+        self.reset_metrics(split='val')
+        return self.last_macro_f1
 
     def evaluate_predictions(self, epoch_loss, split, logging_information=None):
         from sklearn.metrics import classification_report

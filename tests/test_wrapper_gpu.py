@@ -67,3 +67,44 @@ def test_cli_every_shipped_config_runs_and_repeats(config, tmp_path, monkeypatch
     first = cli.main(argv)
     second = cli.main(argv)
     assert len(first) == 6 and first == second
+
+
+def test_cli_two_ranks_print_the_whole_split_metrics_once(tmp_path, monkeypatch, capsys):
+    """Frame-sharded evaluate (BASELINE configs[4]) at world size 2 (two ranks sharing the one GPU over gloo): raw predictions
+    and the per-take / overall classification reports must be those of the single-process run over the whole split --
+    printed once by rank 0, not one partial report per shard."""
+    import re
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from oracle_amd.scene_graph_prediction import main as cli
+    monkeypatch.chdir(tmp_path)
+    argv = ['--config', 'oracle_mv_learned.json', '--model_path', 'synthetic:tiny:chain', '--limit_frames', '13']
+    single = cli.main(argv)
+    one = capsys.readouterr().out
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, ORC_DIST_BACKEND='gloo', PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), '-m', 'oracle_amd.scene_graph_prediction.main', '--mode', 'infer'] + argv,
+                       capture_output=True, text=True, timeout=600, env=env, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr[-3000:]
+    import json
+    merged = json.load(open(tmp_path / 'scan_relations_oracle_mv_learned_test.json'))
+    # 'infer' runs the unlabeled test split; the evaluate split must agree too:
+    r2 = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                         '--master-port', str(port), '-m', 'oracle_amd.scene_graph_prediction.main'] + argv,
+                        capture_output=True, text=True, timeout=600, env=env, cwd=tmp_path)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    two = r2.stdout
+    assert len(merged) == 13
+    tail = lambda text: re.sub(r'\s+', ' ', text[text.rindex('val Results:'):]).strip()
+    assert two.count('val Results:') == 1 and one.count('val Results:') == 1
+    assert tail(one) == tail(two)
+    takes = lambda text: sorted(re.findall(r'Take (\d+)', text))
+    assert takes(one) == takes(two) and len(takes(one)) >= 1
+    assert len(single) == 13
