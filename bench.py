@@ -150,8 +150,53 @@ def self_check(model, eng, input_ids, images, new, n=32, tol=2e-2):
         ok = ok and gap <= tol
         if s + 1 < n:
             logits = eng.decode_step(ref[s:s + 1], want_logits=True).float()
-    return {'result': 'ok' if ok else 'FAILED', 'row0_tokens_identical_prefix': identical, 'steps': n,
-            'worst_gap_to_batch1_argmax_rel': worst, 'tol': tol}
+    # strict part: the same rows in a batch of a different size that takes the SAME kernels (batch - 2 rows: still the
+    # un-split decode attention when (batch - 2) * heads >= 192) must give bit-identical tokens -- rows do not see each other
+    k = new.shape[0] - 2
+    strict = None
+    if k >= 1:
+        part = model.generate(input_ids[:k], images=images[:k], do_sample=False, use_cache=True, max_new_tokens=n, chunk=n)[:, L:L + n]
+        strict = bool(torch.equal(part, new[:k, :n].to(part.device)))
+        ok = ok and strict
+    return {'result': 'ok' if ok else 'FAILED', 'row0_alone_tokens_identical_prefix': identical, 'steps': n,
+            'row0_alone_worst_gap_to_argmax_rel': worst, 'tol': tol, f'first_{k}_rows_in_batch_of_{k}_bit_identical': strict}
+
+
+def ragged_lengths(n, seed, cap):
+    """Per-frame answer lengths drawn (seeded, with replacement) from the 4D-OR validation answers
+    (tests/golden/answer_lengths_4dor_val.json, generated by oracle/gen_answer_lengths.py from the reference's
+    data/relationships_validation.json; shape of the distribution from the data, scale = mean 150 tokens as SURVEY.md 8d)."""
+    import random
+    d = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'answer_lengths_4dor_val.json')))
+    rng = random.Random(seed)
+    return [max(2, min(cap, rng.choice(d['tokens_est']))) for _ in range(n)], d
+
+
+def ragged_runs(model, input_ids, images, batch, n_batches, rank):
+    """The same workload with the 4D-OR answer-length distribution instead of a uniform 150 tokens:
+    (a) batch by batch through generate() -- every batch decodes until its longest answer ends (the reference's loop);
+    (b) generate_stream() -- a finished row is refilled with the next frame. Same frames, same per-frame length stops."""
+    import torch
+    lens, d = ragged_lengths(batch * n_batches, 4242 + rank, 300)
+    items = [{'input_ids': input_ids, 'images': images, 'limits': lens[i * batch:(i + 1) * batch]} for i in range(n_batches)]
+    out = {'length_source': 'tests/golden/answer_lengths_4dor_val.json', 'frames': batch * n_batches,
+           'mean_len': sum(lens) / len(lens), 'max_len': max(lens),
+           'mean_longest_of_batch': sum(max(it['limits']) for it in items) / n_batches}
+    for name in ('batch_by_batch', 'slot_refill'):
+        for rep in range(2):                       # first pass = warm-up
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            if name == 'batch_by_batch':
+                res = [model.generate(it['input_ids'], images=it['images'], do_sample=False, use_cache=True, max_new_tokens=300,
+                                      limits=it['limits'], chunk=8) for it in items]
+            else:
+                res = list(model.generate_stream(iter(items), max_new_tokens=300, n_slots=batch, chunk=8))
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        L = input_ids.shape[1]
+        got = [int((r[b, L:] != 0).sum()) for r in res for b in range(batch)]
+        out[name] = {'frames_per_s': batch * n_batches / dt, 'seconds': dt, 'tokens_emitted': sum(got)}
+    return out
 
 
 def launch_ranks(n):
@@ -209,6 +254,10 @@ def main():
     ap.add_argument('--dims', default='full', choices=['full', 'tiny'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-self-check', action='store_true')
+    ap.add_argument('--lengths', default='both', choices=['uniform', 'both'],
+                    help="'both' (default): after the uniform-length headline also run the 4D-OR answer-length distribution "
+                         "(extra.ragged: batch-by-batch vs slot refill); 'uniform': headline only")
+    ap.add_argument('--ragged-batches', type=int, default=4)
     ap.add_argument('--dry-run', action='store_true',
                     help='launcher / rendezvous / gather / max-over-ranks plumbing only (no GPU, no engine): CPU test of the N>1 path')
     a = ap.parse_args()
@@ -250,8 +299,9 @@ def main():
     tok = SynthTokenizer(dims.vocab)
     probe_ids, _ = build_inputs(tok, 1, 1, dims, 'cpu', a.prompt)
     T = probe_ids.shape[1] - 1 + 576
-    eng = Engine(dims, max_batch=a.batch, max_seq=T + a.new_tokens + 8, max_images=a.batch * a.views,
-                 max_new_tokens=max(a.new_tokens, 16), pad_token_id=0, eos_token_id=-1, device=dev)
+    cap_new = max(a.new_tokens, 300 if a.lengths == 'both' else 16)   # the ragged leg decodes up to the reference's 300
+    eng = Engine(dims, max_batch=a.batch, max_seq=T + cap_new + 8, max_images=a.batch * a.views,
+                 max_new_tokens=cap_new, pad_token_id=0, eos_token_id=-1, device=dev)
     eng.load_state(state)
     del state
     torch.cuda.empty_cache()
@@ -315,6 +365,9 @@ def main():
     torch.cuda.synchronize()
     t_dec = time.perf_counter() - s0
 
+    ragged = None
+    if rank == 0 and a.lengths == 'both' and a.batch > 1:
+        ragged = ragged_runs(model, input_ids, images, a.batch, a.ragged_batches, rank)
     check = None
     if rank == 0 and a.batch > 1 and not a.no_self_check:
         check = self_check(model, eng, input_ids, images, new)
@@ -352,6 +405,8 @@ def main():
                          'traffic': traffic, 'traffic_source': traffic_src, 'launches_timed': prof_n, 'avg_launch_us': avg_us,
                          'algorithmic_bytes_per_launch': prof_bytes},
         }
+        if ragged is not None:
+            res['extra'] = {'ragged': ragged}
         if check is not None:
             res['self_check'] = check['result']
             res['self_check_detail'] = check

@@ -114,6 +114,25 @@ int orc_decode_steps(orc_engine* e, int n_steps, void* stream);
 int orc_read_state(orc_engine* e, int32_t* tokens_host, int32_t* steps_host, int32_t* n_unfinished_host,
                    int32_t* last_argmax_host, void* stream);
 
+/* per-row length stops of the running batch (after orc_prefill; default = max_new_tokens for every row): row b is finished
+ * once it has emitted limits_host[b] tokens (>= 2: the first token is sampled by the prefill itself) or EOS, whichever comes
+ * first -- what max_new_tokens is to the whole batch in the reference's generate() call
+ * (scene_graph_prediction_model_oracle.py:135-143), per row; used for synthetic answer-length distributions. */
+int orc_set_row_limits(orc_engine* e, const int32_t* limits_host, int n, void* stream);
+
+/* Continuous batching over the reference's outer loop (`for batch in dataloader: self.forward(batch)`,
+ * scene_graph_prediction_model_oracle.py:251-260): frames are independent, so a row slot whose frame has finished (EOS or
+ * its length stop) is refilled with the next frame while the other rows keep decoding. Every row keeps its own cached
+ * length, step counter and length stop on the device; a finished row freezes (no cache growth, no cache reads).
+ * orc_stream_begin: n_slots empty rows. orc_prefill_slot: LlavaLlamaForCausalLM.forward step 0 for ONE unpadded row
+ * (embeds (T, d_model), positions 0..T-1) into row `slot`: fills that row's KV cache, resets its greedy state with the
+ * length stop max_new (<= max_new_tokens; T + max_new <= max_seq), samples its first token. orc_decode_steps then advances
+ * every unfinished row. orc_read_slots: synchronises and reads tokens (n_slots * max_new_tokens, pad-filled), tokens
+ * emitted per row, unfinished flags. orc_prefill (a whole left-padded batch) ends the stream. */
+int orc_stream_begin(orc_engine* e, int n_slots, void* stream);
+int orc_prefill_slot(orc_engine* e, int slot, const void* embeds, int T, int max_new, float* logits_out, void* stream);
+int orc_read_slots(orc_engine* e, int32_t* tokens_host, int32_t* row_steps_host, int32_t* unfinished_host, void* stream);
+
 /* test / profiling hooks for single kernels (same kernels the engine runs). */
 int orc_test_gemm(const void* x, int M, int K, const void* w_rowmajor, int N, const void* bias, const void* residual,
                   int epilogue, int use_gemv, void* out, void* stream);

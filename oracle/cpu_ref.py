@@ -274,7 +274,7 @@ def _rot_half(x):
     return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
 
 
-def llama_forward(st, d, inputs_embeds, mask_full, position_ids, kv=None, all_logits=False):
+def llama_forward(st, d, inputs_embeds, mask_full, position_ids, kv=None, all_logits=False, return_hidden=False):
     """One LlamaForCausalLM.forward. inputs_embeds (B,T,D) are the NEW positions; mask_full (B, past+T) bool
     covers cached + new keys; kv = list of (k,v) per layer (K cached after RoPE) or None.
     Returns (logits fp32 (B,V) at the last position or (B,T,V), new_kv)."""
@@ -317,6 +317,8 @@ def llama_forward(st, d, inputs_embeds, mask_full, position_ids, kv=None, all_lo
     h = _rms(h, st['model.norm.weight'], d.rms_eps)
     if not all_logits:
         h = h[:, -1:]
+    if return_hidden:          # the lm_head input (final RMSNorm output) of the last position: calibration of synthetic weights
+        return h[:, -1].float(), new_kv
     logits = F.linear(h, st['lm_head.weight']).float()
     return (logits if all_logits else logits[:, 0]), new_kv
 

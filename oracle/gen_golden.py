@@ -16,7 +16,7 @@ import torch
 from oracle import cpu_ref as cr
 from oracle import ref_harness as rh
 from oracle_amd.dims import TINY, Dims
-from oracle_amd.synth import CHAIN_BASE, CHAIN_LEN, install_chain, synth_images, synth_state
+from oracle_amd.synth import CHAIN_BASE, CHAIN_LEN, install_chain, install_select_chains, synth_images, synth_state
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
 
@@ -328,6 +328,70 @@ def gen_llm_wide_batch():
     save('llm_wide_batch_bfloat16', **out)
 
 
+def select_prompts(n, seed, tail=0):
+    """n left-padded prompts `BOS text(3..14 tokens) <image> [tail text tokens]`: with tail == 0 the image placeholder is
+    the last prompt token (the first answer token is selected by the last image-token row, install_select_chains)."""
+    g = torch.Generator().manual_seed(seed)
+    rows = []
+    for _ in range(n):
+        k = int(torch.randint(3, 15, (1,), generator=g))
+        rows.append([1] + torch.randint(3, 19000, (k,), generator=g).tolist() + [-200]
+                    + torch.randint(3, 19000, (tail,), generator=g).tolist())
+    L = max(len(r) for r in rows)
+    return torch.tensor([[0] * (L - len(r)) + r for r in rows])
+
+
+def select_center(st):
+    """Mean lm_head input of the last prefill position over 8 calibration frames (fp32 math on the bf16-valued weights)."""
+    st32 = {k: v.float() for k, v in st.items()}
+    ids = select_prompts(8, 300)
+    imgs = synth_images(8, 3, TINY, seed=6000).float()
+    with torch.inference_mode():
+        feats = cr.encode_image_features(st32, TINY, imgs, 'learned')
+        emb, mask, pos, _ = cr.splice(st32, ids, ids != 0, feats)
+        h, _ = cr.llama_forward(st32, TINY, emb, mask, pos, return_hidden=True)
+    return h.mean(0)
+
+
+SELECT_FRAMES, SELECT_BATCH = 128, 16
+
+
+def gen_select():
+    """Token identity as a RATE over a population of frames whose answer depends on the image:
+    128 frames (8 ragged batches of 16) through the REAL reference's generate() on install_select_chains weights; stored:
+    prompts, generated tokens, the first step's top-2 logits (the margin the selection was made with)."""
+    dtype = torch.bfloat16
+    base = synth_state(TINY, seed=0, dtype=dtype)
+    center = select_center(base)
+    st = install_select_chains(base, TINY, center=center)
+    model, cfg = rh.build_reference_model(TINY, st, dtype=dtype)
+    out = {'center': center.numpy()}
+    for tag, n, tail, seed in (('last', SELECT_FRAMES, 0, 310),):
+        ids_all, gen_all, top2_all, absmax_all = [], [], [], []
+        for b0 in range(0, n, SELECT_BATCH):
+            ids = select_prompts(SELECT_BATCH, seed * 100 + b0, tail)
+            imgs = synth_images(SELECT_BATCH, 3, TINY, seed=7000 + (0 if tail == 0 else 5000) + b0).to(dtype)
+            with torch.inference_mode():
+                r = model.generate(ids, images=imgs, do_sample=False, use_cache=True, max_new_tokens=24,
+                                   past_key_values=rh.legacy_cache(cfg), output_scores=True, return_dict_in_generate=True)
+            new = r.sequences[:, ids.shape[1]:]
+            new = torch.cat([new, new.new_zeros(new.shape[0], 24 - new.shape[1])], dim=1)       # pad to a fixed width
+            s0 = r.scores[0].float()
+            ids_all.append(torch.cat([ids.new_zeros(ids.shape[0], 16 + tail - ids.shape[1]), ids], dim=1))
+            gen_all.append(new)
+            top2_all.append(torch.topk(s0, 2, dim=-1).values)
+            absmax_all.append(s0.abs().max(-1).values)
+            if b0 == 0:
+                mine = cr.greedy_generate(st, TINY, ids, imgs, max_new_tokens=24)
+                assert torch.equal(mine[:, ids.shape[1]:], r.sequences[:, ids.shape[1]:]), tag
+            print(tag, b0, 'first tokens', new[:, 0].tolist())
+        out[f'{tag}.ids'] = torch.cat(ids_all).numpy()
+        out[f'{tag}.generated'] = torch.cat(gen_all).numpy()
+        out[f'{tag}.top2'] = torch.cat(top2_all).numpy()
+        out[f'{tag}.absmax'] = torch.cat(absmax_all).numpy()
+    save('select_tiny_bfloat16', **out)
+
+
 def chain_prompts():
     ends = [CHAIN_BASE + CHAIN_LEN - 9, CHAIN_BASE + CHAIN_LEN - 30, CHAIN_BASE + CHAIN_LEN - 17]
     rows = [[1, 5, 6, -200, 7, 8, 9, 10, ends[0]], [1, 21, -200, 22, ends[1]], [1, 31, 32, 33, 34, 35, -200, 36, 37, 38, 39, ends[2]]]
@@ -406,6 +470,7 @@ ALL = {
     'llm_bf16': lambda: gen_llm('bfloat16'),
     'llm_wide': gen_llm_wide,
     'llm_batchwide': gen_llm_wide_batch,
+    'select': gen_select,
     'text': gen_text,
 }
 

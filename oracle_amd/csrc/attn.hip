@@ -252,8 +252,20 @@ __global__ __launch_bounds__(WAVES * 64) void decode_attn_kernel(DecodeAttnArgs 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int kq = lane >> 4, c = lane & 15;
   const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z, nsplit = gridDim.z;
-  const int len = *a.cur_len;
+  const int len = a.cur_len[b];
   const int kb = a.kbeg[b];
+  if (a.unfinished && !a.unfinished[b]) {   // finished row (its tokens are pad from here on): no cache read at all
+    if (tid < 128) {
+      if (nsplit == 1) {
+        a.O[a.o_xf ? xf_off(b, h * 128 + tid) : (size_t)b * a.o_bs + h * 128 + tid] = 0;
+      } else {
+        float* pp = a.part + (((size_t)b * a.H + h) * DECODE_NSPLIT + sp) * 130;
+        if (tid == 0) { pp[0] = -INFINITY; pp[1] = 0.f; }
+        pp[2 + tid] = 0.f;
+      }
+    }
+    return;
+  }
   const int n = len - kb;
   const int per = (n + nsplit - 1) / nsplit;
   const int k_lo = kb + sp * per;

@@ -53,10 +53,14 @@ struct PoolLayer {
 };
 struct LlamaLayer {
   bf16_t *ln_in, *ln_post;
-  Packed qkv, qkv_dec, o, gu, down;
+  Packed qkv, qkv_dec, o, gu, gu_dec, down;   // *_dec: decode copies with the preceding RMSNorm weight folded into the columns
 };
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// dev_ints layout (ints): 16 header, then per-row arrays of 16 rows each, then tokens [16][max_new_tokens]
+enum { DI_UNF = 16, DI_NEXT = 32, DI_ARGMAX = 48, DI_KBEG = 64, DI_KEND = 80, DI_ROWOFF = 96, DI_ROWVALID = 112,
+       DI_CURLEN = 128, DI_ROWSTEP = 144, DI_LIMIT = 160, DI_TOKENS = 192 };
 
 }  // namespace
 
@@ -80,7 +84,7 @@ struct orc_engine {
   bf16_t* embed = nullptr;
   std::vector<LlamaLayer> llama;
   bf16_t* final_norm = nullptr;
-  Packed lm_head;
+  Packed lm_head, lm_head_dec;
   bf16_t *cos_tab = nullptr, *sin_tab = nullptr;
   int maxpos = 0;
 
@@ -95,9 +99,13 @@ struct orc_engine {
   float* w_logits = nullptr;
   float* w_part = nullptr;
   float* d_ssq = nullptr;   // [16][d_model/16] per-n-tile sums of squares of the decode hidden state
+  bf16_t* d_hxf = nullptr;   // decode hidden rows in the fragment-ordered layout (input of the norm-folded projections)
   bf16_t *d_h = nullptr, *d_xn = nullptr, *d_qkv = nullptr, *d_att = nullptr, *d_mlp = nullptr;   // decode (<=16 rows)
-  int *dev_ints = nullptr;   // [0]=step [1]=cur_len [2]=n_unfinished, then per-row arrays
-  int *d_step, *d_curlen, *d_nunf, *d_unf, *d_next, *d_argmax, *d_kbeg, *d_kend, *d_rowoff, *d_rowvalid, *d_tokens;
+  int *dev_ints = nullptr;   // [0]=step [2]=n_unfinished, then per-row arrays of 16 (DI_* offsets), then the token buffer
+  int *d_step, *d_nunf, *d_unf, *d_next, *d_argmax, *d_kbeg, *d_kend, *d_rowoff, *d_rowvalid, *d_curlen, *d_rowstep, *d_limit, *d_tokens;
+  int* d_iota = nullptr;     // 0, 1, 2, ... max_seq-1: position ids of an unpadded row (orc_prefill_slot)
+  bool stream_mode = false;  // continuous batching (orc_stream_begin): rows are (re)filled one at a time
+  int slot_T[16] = {0};
   int* h_pinned = nullptr;   // pinned host staging (small int arrays)
   int cur_batch = 0, cur_T = 0;
   int steps_issued = 0;   // decode steps enqueued since the last prefill (host-side mirror of the device cur_len - T)
@@ -139,7 +147,7 @@ int take(orc_engine* e, const std::string& name, bf16_t** dst, size_t expect_num
 
 // concatenate row-major matrices along rows into a temp, pack, free the temp
 int pack_rows(orc_engine* e, const std::vector<std::string>& names, int K, const std::vector<int>* rowmap_host, int align_n,
-              Packed* out) {
+              Packed* out, const bf16_t* colscale = nullptr) {
   int nsrc = 0;
   std::vector<Raw*> rs;
   for (auto& n : names) {
@@ -174,7 +182,7 @@ int pack_rows(orc_engine* e, const std::vector<std::string>& names, int K, const
   }
   bf16_t* wp;
   ORCCHK(e->alloc((void**)&wp, (size_t)Np * Kp * 2));
-  HIPCHK(launch_pack_weight(src, nsrc, K, rm, wp, Np, Kp, 0));
+  HIPCHK(launch_pack_weight(src, nsrc, K, rm, wp, Np, Kp, 0, colscale));
   HIPCHK(hipDeviceSynchronize());
   if (tmp) HIPCHK(hipFree(tmp));
   if (rm) HIPCHK(hipFree(rm));
@@ -239,6 +247,7 @@ extern "C" int orc_engine_create(const orc_config* cfg, orc_engine** out) {
   if (c.max_batch < 1 || c.max_batch > 16) return fail("orc_engine_create", "max_batch must be in 1..16");
   if (c.d_model % 256 || c.d_ff % 64 || c.vocab % 128 || c.clip_d % 128 || c.clip_ff % 128 || c.pool_ff % 128)
     return fail("orc_engine_create", "widths must be multiples of 128 (d_model: 256, i.e. an even head count; d_ff: 64)");
+  if (c.d_model > 4096) return fail("orc_engine_create", "d_model above 4096 is not supported (decode row-scale partials: d_model / 16 <= 256)");
   if (c.max_seq < 2 || c.max_new_tokens < 1 || c.max_images < 1) return fail("orc_engine_create", "capacities must be positive");
   if (c.clip_image % c.clip_patch) return fail("orc_engine_create", "image size not a multiple of the patch size");
   orc_engine* e = new orc_engine();
@@ -367,6 +376,7 @@ extern "C" int orc_engine_finalize(orc_engine* e) {
   ORCCHK(take(e, "model.embed_tokens.weight", &e->embed, (size_t)c.vocab * c.d_model));
   ORCCHK(take(e, "model.norm.weight", &e->final_norm, c.d_model));
   ORCCHK(pack_rows(e, {"lm_head.weight"}, c.d_model, nullptr, 256, &e->lm_head));
+  ORCCHK(pack_rows(e, {"lm_head.weight"}, c.d_model, nullptr, 256, &e->lm_head_dec, e->final_norm));
   free_raw(e, {"lm_head.weight"});
   e->llama.resize(c.n_layers);
   std::vector<int> gu_map(2 * c.d_ff);
@@ -389,10 +399,11 @@ extern "C" int orc_engine_finalize(orc_engine* e) {
     ORCCHK(take(e, q + "post_attention_layernorm.weight", &L.ln_post, c.d_model));
     std::vector<std::string> w3 = {q + "self_attn.q_proj.weight", q + "self_attn.k_proj.weight", q + "self_attn.v_proj.weight"};
     ORCCHK(pack_rows(e, w3, c.d_model, nullptr, 256, &L.qkv));
-    ORCCHK(pack_rows(e, w3, c.d_model, &qkv_dec_map, 256, &L.qkv_dec));
+    ORCCHK(pack_rows(e, w3, c.d_model, &qkv_dec_map, 256, &L.qkv_dec, L.ln_in));
     ORCCHK(pack_rows(e, {q + "self_attn.o_proj.weight"}, c.d_model, nullptr, 256, &L.o));
     std::vector<std::string> w2 = {q + "mlp.gate_proj.weight", q + "mlp.up_proj.weight"};
     ORCCHK(pack_rows(e, w2, c.d_model, &gu_map, 256, &L.gu));
+    ORCCHK(pack_rows(e, w2, c.d_model, &gu_map, 256, &L.gu_dec, L.ln_post));
     ORCCHK(pack_rows(e, {q + "mlp.down_proj.weight"}, c.d_ff, nullptr, 256, &L.down));
     w3.push_back(q + "self_attn.o_proj.weight");
     w3.push_back(w2[0]);
@@ -450,20 +461,28 @@ extern "C" int orc_engine_finalize(orc_engine* e) {
     ORCCHK(e->alloc((void**)&e->w_part, (size_t)16 * c.n_heads * DECODE_NSPLIT * 130 * 4));
     ORCCHK(e->alloc((void**)&e->d_ssq, (size_t)16 * (c.d_model / 16) * 4));
     ORCCHK(e->alloc((void**)&e->d_h, (size_t)16 * c.d_model * 2));
+    ORCCHK(e->alloc((void**)&e->d_hxf, (size_t)16 * c.d_model * 2));
+    HIPCHK(hipMemset(e->d_hxf, 0, (size_t)16 * c.d_model * 2));
     ORCCHK(e->alloc((void**)&e->d_xn, (size_t)16 * c.d_model * 2));
     ORCCHK(e->alloc((void**)&e->d_att, (size_t)16 * c.d_model * 2));
     ORCCHK(e->alloc((void**)&e->d_qkv, (size_t)16 * c.d_model * 3 * 2));
     ORCCHK(e->alloc((void**)&e->d_mlp, (size_t)16 * c.d_ff * 2));
-    const size_t nint = 16 + 16 * 8 + (size_t)16 * c.max_new_tokens;
+    const size_t nint = DI_TOKENS + (size_t)16 * c.max_new_tokens;
     ORCCHK(e->alloc((void**)&e->dev_ints, nint * 4));
     HIPCHK(hipMemset(e->dev_ints, 0, nint * 4));
-    e->d_step = e->dev_ints;
-    e->d_curlen = e->dev_ints + 1;
-    e->d_nunf = e->dev_ints + 2;
-    int* base = e->dev_ints + 16;
-    e->d_unf = base; e->d_next = base + 16; e->d_argmax = base + 32; e->d_kbeg = base + 48;
-    e->d_kend = base + 64; e->d_rowoff = base + 80; e->d_rowvalid = base + 96;
-    e->d_tokens = base + 128;
+    int* di = e->dev_ints;
+    e->d_step = di;
+    e->d_nunf = di + 2;
+    e->d_unf = di + DI_UNF; e->d_next = di + DI_NEXT; e->d_argmax = di + DI_ARGMAX; e->d_kbeg = di + DI_KBEG;
+    e->d_kend = di + DI_KEND; e->d_rowoff = di + DI_ROWOFF; e->d_rowvalid = di + DI_ROWVALID;
+    e->d_curlen = di + DI_CURLEN; e->d_rowstep = di + DI_ROWSTEP; e->d_limit = di + DI_LIMIT;
+    e->d_tokens = di + DI_TOKENS;
+    {
+      std::vector<int> iota(c.max_seq);
+      for (int i = 0; i < c.max_seq; ++i) iota[i] = i;
+      ORCCHK(e->alloc((void**)&e->d_iota, (size_t)c.max_seq * 4));
+      HIPCHK(hipMemcpy(e->d_iota, iota.data(), (size_t)c.max_seq * 4, hipMemcpyHostToDevice));
+    }
     HIPCHK(hipHostMalloc((void**)&e->h_pinned, 4096, hipHostMallocDefault));
   }
   HIPCHK(hipDeviceSynchronize());
@@ -607,12 +626,15 @@ extern "C" int orc_splice(orc_engine* e, const int32_t* codes, int rows, const v
 }
 
 // ============================================================================ LLaMA
+// ssq_in: fold the RMSNorm of the input rows into this projection (W must be the matching *_dec copy); C_xf: EPI_RESIDUAL also
+// writes the new hidden rows fragment-ordered
 static int gemv_ex(orc_engine* e, const bf16_t* X, int ldx, const Packed& W, const bf16_t* R, void* C, int ldc, int M, int epi,
                    hipStream_t s, bf16_t* kc = nullptr, bf16_t* vc = nullptr, float* ssq_out = nullptr, int x_xf = 0, int c_xf = 0,
-                   hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
+                   hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, const float* ssq_in = nullptr, bf16_t* C_xf = nullptr) {
   const orc_config& c = e->c;
   GemvArgs a = {};
   a.x_xf = x_xf; a.c_xf = c_xf; a.ev_start = ev_start; a.ev_stop = ev_stop;
+  a.ssq_in = ssq_in; a.n_part = c.d_model / 16; a.norm_d = c.d_model; a.norm_eps = c.rms_eps; a.C_xf = C_xf;
   a.X = X; a.ldx = ldx; a.Wp = W.p; a.bias = nullptr; a.R = R; a.ldr = ldc; a.C = C; a.ldc = ldc;
   a.M = M; a.N = W.N; a.K = W.K; a.Nvalid = (epi == EPI_SWIGLU) ? W.Nvalid / 2 : W.Nvalid;
   a.H = c.n_heads; a.kbeg = e->d_kbeg; a.cur_len = e->d_curlen; a.cos_tab = e->cos_tab; a.sin_tab = e->sin_tab;
@@ -624,18 +646,19 @@ static int gemv_ex(orc_engine* e, const bf16_t* X, int ldx, const Packed& W, con
 }
 
 // prefill: tiled MFMA GEMMs + flash attention over all B*T positions
+// row0: first row slot of the KV cache / per-row state the B rows go to (0 for a batch prefill)
 static int llama_prefill_layers(orc_engine* e, bf16_t* h, bf16_t* xn, bf16_t* qkv, bf16_t* att, bf16_t* mlp, int B, int T,
-                                const int32_t* pos, hipStream_t s) {
+                                const int32_t* pos, hipStream_t s, int row0 = 0) {
   const orc_config& c = e->c;
   const int d = c.d_model, M = B * T;
   for (int i = 0; i < c.n_layers; ++i) {
     const LlamaLayer& L = e->llama[i];
-    bf16_t* kc = e->kcache + (size_t)i * e->kv_layer_elems;
-    bf16_t* vc = e->vcache + (size_t)i * e->kv_layer_elems;
+    bf16_t* kc = e->kcache + (size_t)i * e->kv_layer_elems + (size_t)row0 * e->c_bs;
+    bf16_t* vc = e->vcache + (size_t)i * e->kv_layer_elems + (size_t)row0 * e->c_bs;
     HIPCHK(launch_rmsnorm(h, d, L.ln_in, xn, d, M, d, c.rms_eps, s));
     ORCCHK(gemm(xn, d, L.qkv, nullptr, nullptr, 0, qkv, 3 * d, M, EPI_NONE, s, false));
     RopeArgs r;
-    r.qkv = qkv; r.B = B; r.T = T; r.H = c.n_heads; r.pos = pos; r.kbeg = e->d_kbeg; r.cur_len = e->d_curlen;
+    r.qkv = qkv; r.B = B; r.T = T; r.H = c.n_heads; r.pos = pos; r.kbeg = e->d_kbeg + row0; r.cur_len = e->d_curlen + row0;
     r.cos_tab = e->cos_tab; r.sin_tab = e->sin_tab; r.maxpos = e->maxpos; r.Kc = kc; r.Vc = vc; r.c_bs = e->c_bs; r.c_hs = e->c_hs;
     r.t0 = 0;
     HIPCHK(launch_rope_kv(r, s));
@@ -644,7 +667,7 @@ static int llama_prefill_layers(orc_engine* e, bf16_t* h, bf16_t* xn, bf16_t* qk
     a.K = kc; a.k_bs = e->c_bs; a.k_hs = e->c_hs; a.k_ts = 128;
     a.V = vc; a.v_bs = e->c_bs; a.v_hs = e->c_hs; a.v_ts = 128;
     a.O = att; a.o_bs = (long)T * d; a.o_hs = 128; a.o_ts = d;
-    a.B = B; a.H = c.n_heads; a.Sq = T; a.Sk = T; a.kbeg = e->d_kbeg; a.kend = nullptr; a.causal = 1; a.q_off = 0;
+    a.B = B; a.H = c.n_heads; a.Sq = T; a.Sk = T; a.kbeg = e->d_kbeg + row0; a.kend = nullptr; a.causal = 1; a.q_off = 0;
     a.scale = 0.08838834764831845f;
     HIPCHK(launch_attention(a, 128, s));
     ORCCHK(gemm(att, d, L.o, nullptr, h, d, h, d, M, EPI_RESIDUAL, s, false));
@@ -655,56 +678,83 @@ static int llama_prefill_layers(orc_engine* e, bf16_t* h, bf16_t* xn, bf16_t* qk
   return 0;
 }
 
-// decode: 7 launches per layer; the activations between them (d_xn, d_att, d_mlp) are kept in the fragment-ordered
+// decode: 5 launches per layer; the activations between them (d_hxf, d_att, d_mlp) are kept in the fragment-ordered
 // layout of common.h xf_off, written so by their producers --
-//   [RMSNorm from partials] [qkv GEMV + rotary + KV write] [attention over the cache] [o_proj GEMV + residual + ssq partials]
-//   [RMSNorm from partials] [gate/up GEMV + SiLU*mul] [down GEMV + residual + ssq partials]
-// The residual epilogues leave per-n-tile sums of squares of the new hidden state in d_ssq, so the norms are
-// elementwise (no reduction pass, many small workgroups).
-static int llama_decode_layers(orc_engine* e, int B, hipStream_t s) {
+//   [qkv GEMV (input RMSNorm folded in) + rotary + KV write] [attention over the cache]
+//   [o_proj GEMV + residual + ssq partials] [gate/up GEMV (post-attention RMSNorm folded in) + SiLU*mul]
+//   [down GEMV + residual + ssq partials]
+// The residual epilogues leave per-n-tile sums of squares of the new hidden state in d_ssq and the hidden rows themselves
+// fragment-ordered in d_hxf; the projection that follows reads the RAW rows, its weight copy carries the norm weight
+// (W' = bf16(W * w_norm)) and its epilogue multiplies row b by rsqrt(mean(h_b^2) + eps) before the first rounding.
+// Rounding points that move against the reference's eager RMSNorm -> Linear: the normalised activation is no longer
+// rounded to bf16 twice (after the scale, after the weight), the folded weight is rounded once more instead.
+static int llama_decode_layers(orc_engine* e, int B, hipStream_t s, bool skip_finished) {
   const orc_config& c = e->c;
-  const int d = c.d_model, np = d / 16;
-  bf16_t *h = e->d_h, *xn = e->d_xn, *q = e->d_qkv, *att = e->d_att, *mlp = e->d_mlp;
+  const int d = c.d_model;
+  bf16_t *h = e->d_h, *hxf = e->d_hxf, *q = e->d_qkv, *att = e->d_att, *mlp = e->d_mlp;
   for (int i = 0; i < c.n_layers; ++i) {
     const LlamaLayer& L = e->llama[i];
     bf16_t* kc = e->kcache + (size_t)i * e->kv_layer_elems;
     bf16_t* vc = e->vcache + (size_t)i * e->kv_layer_elems;
-    HIPCHK(launch_rmsnorm_part(h, d, e->d_ssq, np, L.ln_in, xn, d, B, d, c.rms_eps, s, 1));
-    ORCCHK(gemv_ex(e, xn, d, L.qkv_dec, nullptr, q, d, B, EPI_ROPE_KV, s, kc, vc, nullptr, 1));
+    ORCCHK(gemv_ex(e, hxf, d, L.qkv_dec, nullptr, q, d, B, EPI_ROPE_KV, s, kc, vc, nullptr, 1, 0, nullptr, nullptr, e->d_ssq));
     DecodeAttnArgs a;
     a.o_xf = 1;
     a.Q = q; a.q_bs = d; a.Kc = kc; a.Vc = vc; a.c_bs = e->c_bs; a.c_hs = e->c_hs; a.O = att; a.o_bs = d;
     a.part = e->w_part; a.kbeg = e->d_kbeg; a.cur_len = e->d_curlen; a.B = B; a.H = c.n_heads;
+    a.unfinished = skip_finished ? e->d_unf : nullptr;
     a.scale = 0.08838834764831845f;
     HIPCHK(launch_decode_attention(a, s));
-    ORCCHK(gemv_ex(e, att, d, L.o, h, h, d, B, EPI_RESIDUAL, s, nullptr, nullptr, e->d_ssq, 1));
-    HIPCHK(launch_rmsnorm_part(h, d, e->d_ssq, np, L.ln_post, xn, d, B, d, c.rms_eps, s, 1));
+    ORCCHK(gemv_ex(e, att, d, L.o, h, h, d, B, EPI_RESIDUAL, s, nullptr, nullptr, e->d_ssq, 1, 0, nullptr, nullptr, nullptr, hxf));
     const bool sample = e->prof_on && (i % 8 == 0) && e->ev_used < (int)e->ev_a.size();
     // sampled launches carry their own start / stop events (the dispatch's timestamps, not a pair of event commands
     // around it, which would add the launch boundary)
-    ORCCHK(gemv_ex(e, xn, d, L.gu, nullptr, mlp, c.d_ff, B, EPI_SWIGLU, s, nullptr, nullptr, nullptr, 1, 1,
-                   sample ? e->ev_a[e->ev_used] : nullptr, sample ? e->ev_b[e->ev_used] : nullptr));
+    ORCCHK(gemv_ex(e, hxf, d, L.gu_dec, nullptr, mlp, c.d_ff, B, EPI_SWIGLU, s, nullptr, nullptr, nullptr, 1, 1,
+                   sample ? e->ev_a[e->ev_used] : nullptr, sample ? e->ev_b[e->ev_used] : nullptr, e->d_ssq));
     if (sample) ++e->ev_used;
-    ORCCHK(gemv_ex(e, mlp, c.d_ff, L.down, h, h, d, B, EPI_RESIDUAL, s, nullptr, nullptr, e->d_ssq, 1));
+    ORCCHK(gemv_ex(e, mlp, c.d_ff, L.down, h, h, d, B, EPI_RESIDUAL, s, nullptr, nullptr, e->d_ssq, 1, 0, nullptr, nullptr, nullptr, hxf));
   }
   return 0;
 }
 
-// final RMSNorm + lm_head + greedy sampling. from_decode: hrows = d_h with fresh partials in d_ssq.
-static int head_and_sample(orc_engine* e, const bf16_t* hrows, int ldh, int B, float* logits_out, bool from_decode, hipStream_t s) {
+// final RMSNorm + lm_head + greedy sampling of B rows that live in state rows row0 .. row0 + B - 1.
+// from_decode: hrows = d_h with fresh partials in d_ssq (row0 = 0, B = the whole batch).
+static int head_and_sample(orc_engine* e, const bf16_t* hrows, int ldh, int B, float* logits_out, bool from_decode, hipStream_t s,
+                           int row0 = 0, bool freeze = true) {
   const orc_config& c = e->c;
-  if (from_decode)
-    HIPCHK(launch_rmsnorm_part(hrows, ldh, e->d_ssq, c.d_model / 16, e->final_norm, e->d_xn, c.d_model, B, c.d_model, c.rms_eps, s, 1));
-  else
+  if (from_decode) {   // final RMSNorm folded into the lm_head projection (raw rows in d_hxf, partials in d_ssq)
+    ORCCHK(gemv_ex(e, e->d_hxf, c.d_model, e->lm_head_dec, nullptr, e->w_logits, c.vocab, B, EPI_F32, s, nullptr, nullptr, nullptr, 1, 0,
+                   nullptr, nullptr, e->d_ssq));
+  } else {
     HIPCHK(launch_rmsnorm(hrows, ldh, e->final_norm, e->d_xn, c.d_model, B, c.d_model, c.rms_eps, s));
-  ORCCHK(gemv_ex(e, e->d_xn, c.d_model, e->lm_head, nullptr, e->w_logits, c.vocab, B, EPI_F32, s, nullptr, nullptr, nullptr, from_decode ? 1 : 0));
+    ORCCHK(gemv_ex(e, e->d_xn, c.d_model, e->lm_head, nullptr, e->w_logits, c.vocab, B, EPI_F32, s));
+  }
   if (logits_out)
     HIPCHK(hipMemcpyAsync(logits_out, e->w_logits, (size_t)B * c.vocab * 4, hipMemcpyDeviceToDevice, s));
   SampleArgs a;
-  a.logits = e->w_logits; a.vocab = c.vocab; a.B = B; a.unfinished = e->d_unf; a.next_ids = e->d_next;
-  a.raw_argmax = e->d_argmax; a.out_tokens = e->d_tokens; a.out_ld = c.max_new_tokens; a.step = e->d_step;
-  a.cur_len = e->d_curlen; a.n_unfinished = e->d_nunf; a.pad_id = c.pad_token_id; a.eos_id = c.eos_token_id;
+  a.logits = e->w_logits; a.vocab = c.vocab; a.B = B; a.row0 = row0; a.n_rows = e->cur_batch;
+  a.unfinished = e->d_unf; a.next_ids = e->d_next;
+  a.raw_argmax = e->d_argmax; a.out_tokens = e->d_tokens; a.out_ld = c.max_new_tokens; a.row_step = e->d_rowstep;
+  a.cur_len = e->d_curlen; a.limit = e->d_limit; a.step = e->d_step; a.n_unfinished = e->d_nunf;
+  a.pad_id = c.pad_token_id; a.eos_id = c.eos_token_id; a.freeze_finished = freeze ? 1 : 0;
   HIPCHK(launch_argmax_sample(a, s));
+  return 0;
+}
+
+// uploads the per-row greedy state of rows [row0, row0 + n): unfinished = 1, kbeg, cur_len = T (keys cached after the
+// prefill; sampling advances it to T + 1 for the first decode step), step 0, the length stop; pad-fills their token rows
+static int reset_rows(orc_engine* e, int row0, int n, const int* kbeg_host, int T, int limit, hipStream_t s) {
+  int* hp = e->h_pinned;
+  HIPCHK(hipStreamSynchronize(s));   // pinned staging reuse
+  for (int i = 0; i < n; ++i) {
+    hp[i] = 1; hp[16 + i] = kbeg_host ? kbeg_host[i] : 0; hp[32 + i] = T; hp[48 + i] = 0; hp[64 + i] = limit;
+  }
+  HIPCHK(hipMemcpyAsync(e->d_unf + row0, hp, n * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(e->d_kbeg + row0, hp + 16, n * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(e->d_curlen + row0, hp + 32, n * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(e->d_rowstep + row0, hp + 48, n * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(e->d_limit + row0, hp + 64, n * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(e->d_tokens + (size_t)row0 * e->c.max_new_tokens), e->c.pad_token_id,
+                           (size_t)n * e->c.max_new_tokens, s));
   return 0;
 }
 
@@ -716,23 +766,15 @@ extern "C" int orc_prefill(orc_engine* e, const void* embeds, const int32_t* pos
   if (B < 1 || B > c.max_batch) return fail("orc_prefill", "batch outside 1..max_batch");
   if (T < 1 || T >= c.max_seq) return fail("orc_prefill", "prompt length exceeds max_seq");
   if (B * T > e->ws_rows) return fail("orc_prefill", "batch*T exceeds workspace");
-  HIPCHK(hipStreamSynchronize(s));
-  int* hp = e->h_pinned;
-  for (int i = 0; i < 64; ++i) hp[i] = 0;
-  hp[0] = 0;       // step
-  hp[1] = T;       // cur_len: keys cached after prefill; sampling advances it to T+1 for the first decode step
-  hp[2] = B;
-  for (int b = 0; b < B; ++b) {
+  for (int b = 0; b < B; ++b)
     if (left_pad[b] < 0 || left_pad[b] >= T) return fail("orc_prefill", "left_pad outside 0..T-1");
-    hp[16 + b] = 1;                 // unfinished
-    hp[16 + 48 + b] = left_pad[b];  // kbeg
-  }
-  HIPCHK(hipMemcpyAsync(e->dev_ints, hp, 16 * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(e->d_unf, hp + 16, 16 * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(e->d_kbeg, hp + 16 + 48, 16 * 4, hipMemcpyHostToDevice, s));
+  e->stream_mode = false;
   e->cur_batch = B;
   e->cur_T = T;
   e->steps_issued = 0;
+  HIPCHK(hipMemsetAsync(e->dev_ints, 0, 16 * 4, s));                      // step = 0, n_unfinished set by the sampler
+  HIPCHK(hipMemsetAsync(e->d_unf, 0, 16 * 4, s));                         // rows >= B: finished
+  ORCCHK(reset_rows(e, 0, B, left_pad, T, c.max_new_tokens, s));
   const int d = c.d_model, M = B * T;
   HIPCHK(hipMemcpyAsync(e->w_h, embeds, (size_t)M * d * 2, hipMemcpyDeviceToDevice, s));
   ORCCHK(llama_prefill_layers(e, e->w_h, e->w_xn, e->w_qkv, e->w_att, e->w_mlp, B, T, position_ids, s));
@@ -745,6 +787,7 @@ extern "C" int orc_prefill(orc_engine* e, const void* embeds, const int32_t* pos
 // cache (the device counters are only mirrored here; nothing on the device bounds the slot)
 static int check_capacity(orc_engine* e, int n_steps, const char* who) {
   if (n_steps < 0) return fail(who, "negative step count");
+  if (e->stream_mode) return 0;   // every slot was admitted with T + length stop <= max_seq and freezes at its stop
   if (e->cur_T + e->steps_issued + n_steps > e->c.max_seq) {
     char msg[160];
     snprintf(msg, sizeof(msg), "KV cache full: prompt %d + %d steps taken + %d requested > max_seq %d", e->cur_T, e->steps_issued,
@@ -758,14 +801,17 @@ static int decode_one(orc_engine* e, const int32_t* forced, float* logits_out, h
   const orc_config& c = e->c;
   const int B = e->cur_batch;
   ++e->steps_issued;
-  HIPCHK(launch_embed_tokens(forced ? forced : e->d_next, e->embed, e->d_h, B, c.d_model, c.vocab, e->d_ssq, c.d_model / 16, s));
-  ORCCHK(llama_decode_layers(e, B, s));
-  ORCCHK(head_and_sample(e, e->d_h, c.d_model, B, logits_out, true, s));
+  HIPCHK(launch_embed_tokens(forced ? forced : e->d_next, e->embed, e->d_h, B, c.d_model, c.vocab, e->d_ssq, c.d_model / 16, s, e->d_hxf));
+  // free-running: finished rows freeze (their tokens are pad, their cache is not read or grown); teacher forcing: every
+  // row advances with the forced token whatever the sampler thinks
+  ORCCHK(llama_decode_layers(e, B, s, forced == nullptr));
+  ORCCHK(head_and_sample(e, e->d_h, c.d_model, B, logits_out, true, s, 0, forced == nullptr));
   return 0;
 }
 
 extern "C" int orc_decode_step(orc_engine* e, const int32_t* forced_ids, float* logits_out, void* stream) {
   if (!e || !e->finalized || e->cur_batch == 0) return fail("orc_decode_step", "no prefill has run");
+  if (e->stream_mode && forced_ids) return fail("orc_decode_step", "teacher forcing is not available between orc_stream_begin and the next orc_prefill");
   ORCCHK(check_capacity(e, 1, "orc_decode_step"));
   return decode_one(e, forced_ids, logits_out, S(stream));
 }
@@ -790,6 +836,67 @@ extern "C" int orc_read_state(orc_engine* e, int32_t* tokens_host, int32_t* step
   HIPCHK(hipStreamSynchronize(s));
   if (steps_host) *steps_host = hdr[0];
   if (n_unf_host) *n_unf_host = hdr[2];
+  return 0;
+}
+
+extern "C" int orc_set_row_limits(orc_engine* e, const int32_t* limits_host, int n, void* stream) {
+  if (!e || !e->finalized || e->cur_batch == 0) return fail("orc_set_row_limits", "no prefill has run");
+  if (!limits_host || n != e->cur_batch) return fail("orc_set_row_limits", "one limit per row of the running batch");
+  hipStream_t s = S(stream);
+  HIPCHK(hipStreamSynchronize(s));   // pinned staging reuse
+  for (int i = 0; i < n; ++i) {
+    if (limits_host[i] < 1 || limits_host[i] > e->c.max_new_tokens) return fail("orc_set_row_limits", "limit outside 1..max_new_tokens");
+    e->h_pinned[i] = limits_host[i];
+  }
+  HIPCHK(hipMemcpyAsync(e->d_limit, e->h_pinned, n * 4, hipMemcpyHostToDevice, s));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------- continuous batching
+extern "C" int orc_stream_begin(orc_engine* e, int n_slots, void* stream) {
+  if (!e || !e->finalized) return fail("orc_stream_begin", "engine not finalized");
+  if (n_slots < 1 || n_slots > e->c.max_batch) return fail("orc_stream_begin", "n_slots outside 1..max_batch");
+  hipStream_t s = S(stream);
+  e->stream_mode = true;
+  e->cur_batch = n_slots;
+  e->cur_T = 0;
+  e->steps_issued = 0;
+  for (int i = 0; i < 16; ++i) e->slot_T[i] = 0;
+  // every slot empty = finished, with one harmless cached key so that a decode step over it stays in bounds
+  HIPCHK(hipMemsetAsync(e->dev_ints, 0, DI_TOKENS * 4, s));
+  HIPCHK(hipMemsetD32Async((hipDeviceptr_t)e->d_curlen, 1, 16, s));
+  HIPCHK(hipMemsetD32Async((hipDeviceptr_t)e->d_limit, 1, 16, s));
+  return 0;
+}
+
+extern "C" int orc_prefill_slot(orc_engine* e, int slot, const void* embeds, int T, int max_new, float* logits_out, void* stream) {
+  if (!e || !e->finalized) return fail("orc_prefill_slot", "engine not finalized");
+  if (!e->stream_mode) return fail("orc_prefill_slot", "call orc_stream_begin first");
+  const orc_config& c = e->c;
+  hipStream_t s = S(stream);
+  if (slot < 0 || slot >= e->cur_batch) return fail("orc_prefill_slot", "slot outside the running batch");
+  if (max_new < 1 || max_new > c.max_new_tokens) return fail("orc_prefill_slot", "length stop outside 1..max_new_tokens");
+  if (T < 1 || T + max_new > c.max_seq) return fail("orc_prefill_slot", "prompt + length stop exceeds max_seq");
+  if (T > e->ws_rows) return fail("orc_prefill_slot", "T exceeds workspace");
+  ORCCHK(reset_rows(e, slot, 1, nullptr, T, max_new, s));
+  e->slot_T[slot] = T;
+  const int d = c.d_model;
+  HIPCHK(hipMemcpyAsync(e->w_h, embeds, (size_t)T * d * 2, hipMemcpyDeviceToDevice, s));
+  ORCCHK(llama_prefill_layers(e, e->w_h, e->w_xn, e->w_qkv, e->w_att, e->w_mlp, 1, T, e->d_iota, s, slot));
+  ORCCHK(head_and_sample(e, e->w_h + (size_t)(T - 1) * d, T * d, 1, logits_out, false, s, slot));
+  return 0;
+}
+
+extern "C" int orc_read_slots(orc_engine* e, int32_t* tokens_host, int32_t* row_steps_host, int32_t* unfinished_host,
+                              void* stream) {
+  if (!e || !e->finalized) return fail("orc_read_slots", "engine not finalized");
+  hipStream_t s = S(stream);
+  const int B = e->cur_batch;
+  if (B < 1) return fail("orc_read_slots", "no running batch");
+  if (tokens_host) HIPCHK(hipMemcpyAsync(tokens_host, e->d_tokens, (size_t)B * e->c.max_new_tokens * 4, hipMemcpyDeviceToHost, s));
+  if (row_steps_host) HIPCHK(hipMemcpyAsync(row_steps_host, e->d_rowstep, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+  if (unfinished_host) HIPCHK(hipMemcpyAsync(unfinished_host, e->d_unf, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
   return 0;
 }
 
@@ -902,11 +1009,12 @@ extern "C" int orc_test_decode_attention(const void* q, const void* kcache, cons
   HIPCHK(hipMalloc((void**)&part, (size_t)B * H * DECODE_NSPLIT * 130 * 4));
   HIPCHK(hipMalloc((void**)&ints, 32 * 4));
   int host[32] = {0};
-  host[0] = n_keys;
+  for (int b = 0; b < 16; ++b) host[b] = n_keys;
   HIPCHK(hipMemcpyAsync(ints, host, sizeof(host), hipMemcpyHostToDevice, s));
   if (kbeg) HIPCHK(hipMemcpyAsync(ints + 16, kbeg, B * 4, hipMemcpyDeviceToDevice, s));
   DecodeAttnArgs a;
   a.o_xf = 0;
+  a.unfinished = nullptr;
   a.Q = (const bf16_t*)q; a.q_bs = (long)H * 128; a.Kc = (const bf16_t*)kcache; a.Vc = (const bf16_t*)vcache;
   a.c_hs = (long)Tmax * 128; a.c_bs = a.c_hs * H; a.O = (bf16_t*)out; a.o_bs = (long)H * 128;
   a.part = part; a.kbeg = ints + 16; a.cur_len = ints; a.B = B; a.H = H; a.scale = 0.08838834764831845f;

@@ -405,7 +405,7 @@ __global__ __launch_bounds__(512) void gemm_dma_kernel(GemmArgs a, int n_big, in
 // W[Nsrc][K] row-major (optionally through rowmap: packed row -> source row, -1 = zero row)
 // -> packed blocks [Np/16][Kp/32][64 lanes][8].
 __global__ void pack_weight_kernel(const bf16_t* __restrict__ W, int Nsrc, int K, const int* __restrict__ rowmap,
-                                   bf16_t* __restrict__ Wp, int Np, int Kp) {
+                                   bf16_t* __restrict__ Wp, int Np, int Kp, const bf16_t* __restrict__ colscale) {
   const size_t total = (size_t)Np * (Kp >> 3);
   const int KT = Kp >> 5;
   for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
@@ -419,7 +419,10 @@ __global__ void pack_weight_kernel(const bf16_t* __restrict__ W, int Nsrc, int K
     if (src >= Nsrc) src = -1;
     bf16_t v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (src >= 0 && k + j < K) ? W[(size_t)src * K + k + j] : (bf16_t)0;
+    for (int j = 0; j < 8; ++j) {
+      v[j] = (src >= 0 && k + j < K) ? W[(size_t)src * K + k + j] : (bf16_t)0;
+      if (colscale && k + j < K) v[j] = f2bf(bf2f(v[j]) * bf2f(colscale[k + j]));
+    }
     u32x4 st = {(uint32_t)v[0] | ((uint32_t)v[1] << 16), (uint32_t)v[2] | ((uint32_t)v[3] << 16),
                 (uint32_t)v[4] | ((uint32_t)v[5] << 16), (uint32_t)v[6] | ((uint32_t)v[7] << 16)};
     *(u32x4*)(Wp + o * 8) = st;
@@ -524,11 +527,11 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
 }
 
 hipError_t launch_pack_weight(const bf16_t* W, int Nsrc, int K, const int* rowmap, bf16_t* Wp, int Np, int Kp,
-                              hipStream_t s) {
+                              hipStream_t s, const bf16_t* colscale) {
   if ((Np & 15) || (Kp & 31)) return hipErrorInvalidValue;
   const size_t total = (size_t)Np * (Kp >> 3);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, s, W, Nsrc, K, rowmap, Wp, Np, Kp);
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, s, W, Nsrc, K, rowmap, Wp, Np, Kp, colscale);
   return hipGetLastError();
 }

@@ -23,11 +23,53 @@ namespace {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Row scales of the folded RMSNorm (GemvArgs::ssq_in). The n_part per-tile partials of every row are summed in a fixed
+// order that does not depend on the batch: lane (g, b) of scale wave w (the first SW = min(WAVES, 4) waves) owns the
+// contiguous slice [(g * SW + w) * per, + per) of row b, per = n_part / (4 * SW) <= 16. The loads are the FIRST loads a wave
+// issues (oldest in its in-order queue) and nothing reads them until the wave has finished its first unit, so they cost no
+// stall; the slice sums meet in LDS (sh_ps[w][lane]) and the epilogue wave adds them w-major, g-minor.
+struct ScaleRegs { f32x4 v[4]; };
+template <int SW>
+__device__ __forceinline__ void scale_load(const GemvArgs& a, ScaleRegs& r, int w, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r.v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int g = lane >> 4, b = lane & 15;
+  if (!a.ssq_in || w >= SW || b >= a.M) return;
+  const int per = a.n_part / (4 * SW);
+  const float* p = a.ssq_in + (size_t)b * a.n_part + (g * SW + w) * per;
+  if ((per & 3) == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (4 * i < per) r.v[i] = *(const f32x4*)(p + 4 * i);
+  } else {   // narrow models (n_part < 16 * SW): per is 1 or 2
+    r.v[0][0] = p[0];
+    if (per > 1) r.v[0][1] = p[1];
+  }
+}
+template <int SW>
+__device__ __forceinline__ void scale_park(const GemvArgs& a, const ScaleRegs& r, float (*sh_ps)[64], int w, int lane) {
+  if (!a.ssq_in || w >= SW) return;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { s += r.v[i][0]; s += r.v[i][1]; s += r.v[i][2]; s += r.v[i][3]; }
+  sh_ps[w][lane] = s;
+}
+template <int SW>
+__device__ __forceinline__ float scale_of_row(const GemvArgs& a, const float (*sh_ps)[64], int b) {
+  float s = 0.f;
+#pragma unroll
+  for (int w = 0; w < SW; ++w)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) s += sh_ps[w][g * 16 + b];
+  return rsqrtf(s / (float)a.norm_d + a.norm_eps);
+}
+
 // ---- epilogues. `red` = this unit's partial D tiles [WAVES][NT][64 lanes][4]; a lane holds column b = lane & 15 (batch
 // row) and rows n = 16 * tile + 4 * (lane >> 4) + r of a D tile.
 // Paired epilogues (one wave): tile 0 and tile 1 of the unit are partners (gate / up, or rotary halves).
 template <int NT, int EPI, int WAVES>
-__device__ __forceinline__ void epilogue_pair(const GemvArgs& a, const float (*red)[NT][64][4], int pair, int lane) {
+__device__ __forceinline__ void epilogue_pair(const GemvArgs& a, const float (*red)[NT][64][4], int pair, int lane,
+                                              const float (*sh_ps)[64]) {
   static_assert(NT == 2, "paired tiles");
   const int g = lane >> 4, b = lane & 15;
   f32x4 t0 = f32x4{0.f, 0.f, 0.f, 0.f}, t1 = t0;
@@ -37,6 +79,11 @@ __device__ __forceinline__ void epilogue_pair(const GemvArgs& a, const float (*r
     t1 += *(const f32x4*)&red[i][1][lane][0];
   }
   if (b >= a.M) return;
+  if (a.ssq_in) {   // folded RMSNorm: the row's scale, applied before the first rounding
+    const float rs = scale_of_row<(WAVES < 4 ? WAVES : 4)>(a, sh_ps, b);
+    t0 *= rs;
+    t1 *= rs;
+  }
   if constexpr (EPI == EPI_SWIGLU) {
     const int n = pair * 16 + 4 * g;
     if (n >= a.Nvalid) return;
@@ -53,7 +100,7 @@ __device__ __forceinline__ void epilogue_pair(const GemvArgs& a, const float (*r
     // rows were packed so that tile 0 holds head dims [d0, d0+16) and tile 1 their rotary partners [d0+64, ...)
     const int hs = pair >> 2, d = (pair & 3) * 16 + 4 * g;
     const int sec = hs / a.H, h = hs % a.H;
-    const int len = *a.cur_len;
+    const int len = a.cur_len[b];
     const int pos_raw = len - 1 - a.kbeg[b];
     const int pos = pos_raw < 0 ? 0 : (pos_raw >= a.maxpos ? a.maxpos - 1 : pos_raw);
     const int slot = len - 1;
@@ -88,11 +135,13 @@ __device__ __forceinline__ void epilogue_pair(const GemvArgs& a, const float (*r
 
 // Un-paired epilogues: tile `nt` of the unit (global n-tile index `ntile`), one wave.
 template <int NT, int EPI, int WAVES>
-__device__ __forceinline__ void epilogue_tile(const GemvArgs& a, const float (*red)[NT][64][4], int nt, int ntile, int lane) {
+__device__ __forceinline__ void epilogue_tile(const GemvArgs& a, const float (*red)[NT][64][4], int nt, int ntile, int lane,
+                                              const float (*sh_ps)[64]) {
   const int g = lane >> 4, b = lane & 15;
   f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < WAVES; ++i) v += *(const f32x4*)&red[i][nt][lane][0];
+  if (a.ssq_in) v *= scale_of_row<(WAVES < 4 ? WAVES : 4)>(a, sh_ps, b);   // folded RMSNorm (rows b >= M: sum 0, finite scale)
   const int n = ntile * 16 + 4 * g;
   const bool live = b < a.M && n < a.Nvalid;
   float y[4];
@@ -128,16 +177,23 @@ __device__ __forceinline__ void epilogue_tile(const GemvArgs& a, const float (*r
   } else {
     u32x2 st = {pack2(y[0], y[1]), pack2(y[2], y[3])};
     *(u32x2*)((bf16_t*)a.C + (size_t)b * a.ldc + n) = st;
+    if constexpr (EPI == EPI_RESIDUAL) {
+      if (a.C_xf) *(u32x2*)(a.C_xf + xf_off(b, n)) = st;
+    }
   }
 }
 
 template <int NT, int EPI, int WAVES, int U, int KMODE>
 __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs a) {
   __shared__ __attribute__((aligned(16))) float red[WAVES][NT][64][4];
+  constexpr int SW = WAVES < 4 ? WAVES : 4;
+  __shared__ float sh_ps[SW][64];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int g = lane >> 4, r16 = lane & 15;
   const int KT = a.K >> 5;
   const int ntile0 = blockIdx.x * NT;
+  ScaleRegs sc;
+  scale_load<SW>(a, sc, w, lane);
   // this wave's k-tiles: kt(i) = k0 + i * kstep, i < nk
   int k0, kstep, nk;
   if constexpr (KMODE == 0) {
@@ -204,12 +260,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs a) {
 
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) *(f32x4*)&red[w][nt][lane][0] = acc[nt];
+  scale_park<SW>(a, sc, sh_ps, w, lane);
   __syncthreads();
 
   if constexpr (EPI == EPI_SWIGLU || EPI == EPI_ROPE_KV) {
-    if (w == 0) epilogue_pair<NT, EPI, WAVES>(a, red, blockIdx.x, lane);
+    if (w == 0) epilogue_pair<NT, EPI, WAVES>(a, red, blockIdx.x, lane, sh_ps);
   } else {
-    if (w < NT) epilogue_tile<NT, EPI, WAVES>(a, red, w, ntile0 + w, lane);
+    if (w < NT) epilogue_tile<NT, EPI, WAVES>(a, red, w, ntile0 + w, lane, sh_ps);
   }
 }
 
@@ -222,8 +279,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs a) {
 template <int NT, int EPI, int WAVES, int U>
 __global__ __launch_bounds__(WAVES * 64) void gemv_pers_kernel(GemvArgs a, int units) {
   __shared__ __attribute__((aligned(16))) float red[2][WAVES][NT][64][4];
+  constexpr int SW = WAVES < 4 ? WAVES : 4;
+  __shared__ float sh_ps[SW][64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  ScaleRegs sc;
+  scale_load<SW>(a, sc, w, lane);
   const int g = lane >> 4, r16 = lane & 15;
   const int KT = a.K >> 5;
   const int nk = (KT - w + WAVES - 1) / WAVES;                       // >= 1 (host: KT >= WAVES)
@@ -284,14 +345,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_pers_kernel(GemvArgs a, int u
             *(f32x4*)&rp[w][nt][lane][0] = acc[nt];
             acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
           }
+          if (cj == 0) scale_park<SW>(a, sc, sh_ps, w, lane);      // once, before the first epilogue of the workgroup
           __syncthreads();
           if (w == cj % WAVES) {
             const int unit = blockIdx.x + cj * G;
             if constexpr (EPI == EPI_SWIGLU || EPI == EPI_ROPE_KV) {
-              epilogue_pair<NT, EPI, WAVES>(a, rp, unit, lane);
+              epilogue_pair<NT, EPI, WAVES>(a, rp, unit, lane, sh_ps);
             } else {
 #pragma unroll
-              for (int nt = 0; nt < NT; ++nt) epilogue_tile<NT, EPI, WAVES>(a, rp, nt, unit * NT + nt, lane);
+              for (int nt = 0; nt < NT; ++nt) epilogue_tile<NT, EPI, WAVES>(a, rp, nt, unit * NT + nt, lane, sh_ps);
             }
           }
           ++cj;

@@ -34,19 +34,27 @@ struct GemvArgs {
   // EPI_RESIDUAL: when non-null, ssq_out[b * (N/16) + ntile] = sum of squares of the stored tile values of row b
   float* ssq_out;
   // EPI_ROPE_KV: W rows packed per head-section as (tile j, tile j+4) pairs; C = q output [M][H*128]
-  int H; const int* kbeg; const int* cur_len;
+  int H; const int* kbeg; const int* cur_len;   // cur_len[b]: cached keys of row b incl. the token of this step
   const bf16_t* cos_tab; const bf16_t* sin_tab; int maxpos;
   bf16_t* Kc; bf16_t* Vc; long c_bs, c_hs;
   // decode-path activation buffers in the fragment-ordered layout (common.h xf_off): x_xf = X is, c_xf = C is written so
   // (EPI_SWIGLU only: its output feeds the down projection)
   int x_xf, c_xf;
+  // RMSNorm folded into the projection (decode path): X holds the RAW hidden rows, the weight copy carries the norm weight
+  // (W'[n][k] = bf16(W[n][k] * w_norm[k]), packed at finalize) and, when ssq_in is non-null, every epilogue multiplies
+  // row b by r_b = rsqrt(sum_t ssq_in[b][t] / norm_d + norm_eps) before its first rounding: y = bf16(r_b * sum_k W' h).
+  // ssq_in = the per-n-tile partials the producer of the hidden state left (ssq_out of the residual epilogue / the token gather).
+  const float* ssq_in; int n_part; int norm_d; float norm_eps;
+  // EPI_RESIDUAL: when non-null the new hidden rows are ALSO written in the fragment-ordered layout (input of the next projection)
+  bf16_t* C_xf;
   // optional (host side only): HIP events that bracket exactly this kernel's execution (hipExtLaunchKernelGGL start /
   // stop events = the dispatch's own timestamps, what rocprofv3's kernel trace reports), for orc_profile_read
   void* ev_start; void* ev_stop;
 };
 hipError_t launch_gemv_ex(const GemvArgs& a, int epi, int variant, hipStream_t s);
+// colscale (bf16 [K], may be null): Wp holds bf16(W[n][k] * colscale[k])
 hipError_t launch_pack_weight(const bf16_t* W, int Nsrc, int K, const int* rowmap, bf16_t* Wp, int Np, int Kp,
-                              hipStream_t s);
+                              hipStream_t s, const bf16_t* colscale = nullptr);
 
 // ---- norms
 hipError_t launch_rmsnorm(const bf16_t* x, int ldx, const bf16_t* w, bf16_t* y, int ldy, int rows, int d, float eps,
@@ -81,7 +89,8 @@ struct DecodeAttnArgs {
   bf16_t* O; long o_bs;                      // [B][H*128]
   float* part;                               // workspace [B][H][NSPLIT][2+128]
   const int* kbeg;                           // [B] left-pad offset
-  const int* cur_len;                        // device scalar: number of cached keys incl. the new one
+  const int* cur_len;                        // [B] number of cached keys of each row incl. the new one
+  const int* unfinished;                     // [B] or null: rows whose flag is 0 are skipped (output zeros; their tokens are pad)
   int B, H;
   float scale;
   int o_xf;                                  // write O in the fragment-ordered layout (common.h xf_off), k = h * 128 + d
@@ -92,9 +101,9 @@ hipError_t launch_decode_attention(const DecodeAttnArgs& a, hipStream_t s, int v
 // ---- rotary + KV-cache write. qkv [rows][3*H*128]; row = b*T + t; q rotated in place.
 struct RopeArgs {
   bf16_t* qkv; int B, T, H;
-  const int* pos;             // [B*T] position ids (null: decode mode, pos = *cur_len - 1 - kbeg[b])
+  const int* pos;             // [B*T] position ids (null: decode mode, pos = cur_len[b] - 1 - kbeg[b])
   const int* kbeg;            // decode mode only
-  const int* cur_len;         // decode mode: device scalar; cache slot = *cur_len - 1
+  const int* cur_len;         // decode mode: [B]; cache slot = cur_len[b] - 1
   const bf16_t* cos_tab; const bf16_t* sin_tab;   // [maxpos][64]
   int maxpos;
   bf16_t* Kc; bf16_t* Vc; long c_bs, c_hs;        // cache [B][H][Tmax][128]
@@ -115,9 +124,10 @@ hipError_t launch_copy_rows(const bf16_t* src, long src_bs, bf16_t* dst, long ds
 // splice: out[r][:] = kind==0 ? 0 : table_kind[idx][:]   (code = kind<<28 | idx)
 hipError_t launch_gather_rows(const int* codes, const bf16_t* tok, const bf16_t* img, const bf16_t* desc, bf16_t* out,
                               int rows, int d, hipStream_t s);
-// out[r] = tok[ids[r]]; when ssq_part != null also part[r][0] = sum(out[r]^2), part[r][1..n_part) = 0
+// out[r] = tok[ids[r]]; when ssq_part != null also part[r][0] = sum(out[r]^2), part[r][1..n_part) = 0; when out_xf != null the
+// rows are also written in the fragment-ordered layout (rows <= 16)
 hipError_t launch_embed_tokens(const int* ids, const bf16_t* tok, bf16_t* out, int rows, int d, int vocab,
-                               float* ssq_part, int n_part, hipStream_t s);
+                               float* ssq_part, int n_part, hipStream_t s, bf16_t* out_xf = nullptr);
 hipError_t launch_view_reduce(const bf16_t* x, bf16_t* out, int B, int V, int n, int mode, hipStream_t s);
 hipError_t launch_pool2x2(const bf16_t* x, bf16_t* out, int n_img, int grid, int d, hipStream_t s);
 
@@ -125,16 +135,23 @@ hipError_t launch_pool2x2(const bf16_t* x, bf16_t* out, int n_img, int grid, int
 hipError_t launch_preprocess(const uint8_t* img, int n, int H, int W, int out, const int* bounds, const int* coef, int ksize,
                              const bf16_t* lut, int fr, int fg, int fb, uint8_t* tmp, bf16_t* dst, hipStream_t s);
 
-// ---- greedy sampling state machine (device resident)
+// ---- greedy sampling state machine (device resident, per row: rows of one batch may belong to different frames that
+// started at different times -- continuous batching, orc_prefill_slot)
 struct SampleArgs {
-  const float* logits; int vocab; int B;
-  int* unfinished;     // [B]
-  int* next_ids;       // [B] token fed to the next step
-  int* raw_argmax;     // [B] argmax before the finished-row substitution (may be null)
-  int* out_tokens; int out_ld;   // [B][max_new] generated tokens
-  int* step;           // device scalar, incremented
-  int* cur_len;        // device scalar, incremented (number of cached keys for the NEXT step incl. its token)
+  const float* logits; int vocab;
+  int B;               // rows sampled by this launch: logits row i belongs to state row row0 + i
+  int row0;
+  int n_rows;          // rows of the running batch (for the n_unfinished count)
+  int* unfinished;     // [n_rows]
+  int* next_ids;       // [n_rows] token fed to the next step
+  int* raw_argmax;     // [n_rows] argmax before the finished-row substitution (may be null)
+  int* out_tokens; int out_ld;   // [n_rows][max_new] generated tokens (pre-filled with pad at prefill)
+  int* row_step;       // [n_rows] tokens emitted so far by the frame in this row
+  int* cur_len;        // [n_rows] cached keys for the NEXT step incl. its token
+  const int* limit;    // [n_rows] length stop: the row is finished after emitting limit[b] tokens
+  int* step;           // device scalar: sampling launches since the last batch prefill
   int* n_unfinished;   // device scalar: rows still unfinished after this step
   int pad_id, eos_id;
+  int freeze_finished; // 1: a finished row stops advancing (keeps its cache slot and step); 0: teacher forcing, all rows advance
 };
 hipError_t launch_argmax_sample(const SampleArgs& a, hipStream_t s);

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(RopeArgs a) {
     pos = a.pos[row];
     slot = a.t0 + t;
   } else {
-    const int len = *a.cur_len;
+    const int len = a.cur_len[b];
     pos = len - 1 - a.kbeg[b];
     slot = len - 1;
   }
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(128) void gather_rows_kernel(const int* __restrict_
 
 __global__ __launch_bounds__(128) void embed_tokens_kernel(const int* __restrict__ ids, const bf16_t* __restrict__ tok,
                                                            bf16_t* __restrict__ out, int d, int vocab,
-                                                           float* __restrict__ ssq_part, int n_part) {
+                                                           float* __restrict__ ssq_part, int n_part, bf16_t* __restrict__ out_xf) {
   __shared__ float sh[2];
   const int row = blockIdx.x;
   int id = ids[row];
@@ -171,6 +171,7 @@ __global__ __launch_bounds__(128) void embed_tokens_kernel(const int* __restrict
   for (int c = threadIdx.x; c < (d >> 3); c += 128) {
     const u32x4 v = *(const u32x4*)(tok + (size_t)id * d + c * 8);
     *(u32x4*)(out + (size_t)row * d + c * 8) = v;
+    if (out_xf) *(u32x4*)(out_xf + xf_off(row, c * 8)) = v;
 #pragma unroll
     for (int j = 0; j < 4; ++j) ss += lo_bf(v[j]) * lo_bf(v[j]) + hi_bf(v[j]) * hi_bf(v[j]);
   }
@@ -276,8 +277,8 @@ __global__ __launch_bounds__(128) void resize_v_kernel(const uint8_t* __restrict
 __global__ __launch_bounds__(1024) void argmax_sample_kernel(SampleArgs a) {   // 16 waves per row: 8 loads per thread at 32000
   __shared__ float sv[16];
   __shared__ int si[16];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const float* lg = a.logits + (size_t)b * a.vocab;
+  const int b = a.row0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const float* lg = a.logits + (size_t)blockIdx.x * a.vocab;
   float best = -INFINITY;
   int bi = 0x7fffffff;
   for (int i = tid * 4; i < a.vocab; i += 4096) {
@@ -299,13 +300,17 @@ __global__ __launch_bounds__(1024) void argmax_sample_kernel(SampleArgs a) {   /
     for (int i = 1; i < 16; ++i)
       if (sv[i] > best || (sv[i] == best && si[i] < bi)) { best = sv[i]; bi = si[i]; }
     if (bi == 0x7fffffff) bi = 0;   // all-NaN row: torch.argmax would return the first NaN; keep defined
-    const int step = *a.step;
+    const int step = a.row_step[b];
     const int unf = a.unfinished[b];
     const int nxt = unf ? bi : a.pad_id;
     if (a.raw_argmax) a.raw_argmax[b] = bi;
     a.next_ids[b] = nxt;
-    if (a.out_tokens && step < a.out_ld) a.out_tokens[(size_t)b * a.out_ld + step] = nxt;
-    a.unfinished[b] = unf && (nxt != a.eos_id);
+    if (unf || !a.freeze_finished) {   // per-row state: only this block touches row b
+      if (a.out_tokens && step < a.out_ld) a.out_tokens[(size_t)b * a.out_ld + step] = nxt;
+      a.row_step[b] = step + 1;
+      a.cur_len[b] += 1;
+    }
+    a.unfinished[b] = unf && (nxt != a.eos_id) && (step + 1 < a.limit[b]);
   }
 }
 
@@ -313,10 +318,9 @@ __global__ __launch_bounds__(1024) void argmax_sample_kernel(SampleArgs a) {   /
 __global__ void step_advance_kernel(SampleArgs a) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     int n = 0;
-    for (int b = 0; b < a.B; ++b) n += a.unfinished[b] ? 1 : 0;
+    for (int b = 0; b < a.n_rows; ++b) n += a.unfinished[b] ? 1 : 0;
     *a.n_unfinished = n;
     *a.step += 1;
-    *a.cur_len += 1;
   }
 }
 
@@ -364,9 +368,10 @@ hipError_t launch_gather_rows(const int* codes, const bf16_t* tok, const bf16_t*
   return hipGetLastError();
 }
 hipError_t launch_embed_tokens(const int* ids, const bf16_t* tok, bf16_t* out, int rows, int d, int vocab, float* ssq_part,
-                               int n_part, hipStream_t s) {
+                               int n_part, hipStream_t s, bf16_t* out_xf) {
   if (rows <= 0) return hipSuccess;
-  hipLaunchKernelGGL(embed_tokens_kernel, dim3(rows), dim3(128), 0, s, ids, tok, out, d, vocab, ssq_part, n_part);
+  if (out_xf && rows > 16) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(embed_tokens_kernel, dim3(rows), dim3(128), 0, s, ids, tok, out, d, vocab, ssq_part, n_part, out_xf);
   return hipGetLastError();
 }
 hipError_t launch_view_reduce(const bf16_t* x, bf16_t* out, int B, int V, int n, int mode, hipStream_t s) {

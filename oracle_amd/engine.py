@@ -153,6 +153,10 @@ class Engine:
         self.batch = b
         return logits
 
+    def set_row_limits(self, limits):
+        arr = (C.c_int32 * len(limits))(*[int(x) for x in limits])
+        _lib.check(self.lib.orc_set_row_limits(self._h, arr, len(limits), _stream()), 'orc_set_row_limits')
+
     def decode_step(self, forced_ids=None, want_logits=False):
         f = forced_ids.to(torch.int32).contiguous() if forced_ids is not None else None
         logits = torch.empty(self.batch, self.dims.vocab, dtype=torch.float32, device=self.device) if want_logits else None
@@ -164,13 +168,38 @@ class Engine:
 
     def read_state(self):
         """-> (tokens (B, steps) int64 CPU tensor, steps, n_unfinished, last raw argmax (B,))"""
+        import numpy as np
         b = self.batch
-        toks = (C.c_int32 * (b * self.max_new_tokens))()
+        toks = np.empty((b, self.max_new_tokens), dtype=np.int32)
         steps, nunf = C.c_int32(), C.c_int32()
         am = (C.c_int32 * b)()
-        _lib.check(self.lib.orc_read_state(self._h, toks, C.byref(steps), C.byref(nunf), am, _stream()), 'orc_read_state')
-        t = torch.tensor(list(toks), dtype=torch.long).view(b, self.max_new_tokens)[:, :min(steps.value, self.max_new_tokens)]
+        _lib.check(self.lib.orc_read_state(self._h, toks.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(steps), C.byref(nunf), am,
+                                           _stream()), 'orc_read_state')
+        t = torch.from_numpy(toks).long()[:, :min(steps.value, self.max_new_tokens)]
         return t, steps.value, nunf.value, torch.tensor(list(am), dtype=torch.long)
+
+    # ------------------------------------------------------------------ continuous batching
+    def stream_begin(self, n_slots):
+        _lib.check(self.lib.orc_stream_begin(self._h, int(n_slots), _stream()), 'orc_stream_begin')
+        self.batch = int(n_slots)
+
+    def prefill_slot(self, slot, embeds, max_new, want_logits=False):
+        """embeds (T, D) bf16: one unpadded spliced prompt into row `slot` of the running batch; max_new = its length stop."""
+        _chk_bf16(embeds, 'embeds')
+        t = embeds.shape[0]
+        logits = torch.empty(1, self.dims.vocab, dtype=torch.float32, device=embeds.device) if want_logits else None
+        _lib.check(self.lib.orc_prefill_slot(self._h, int(slot), _ptr(embeds), t, int(max_new), _ptr(logits), _stream()), 'orc_prefill_slot')
+        return logits
+
+    def read_slots(self):
+        """-> (tokens (n_slots, max_new_tokens) int64 CPU tensor, tokens emitted per row (list), unfinished flags (list))"""
+        import numpy as np
+        b = self.batch
+        toks = np.empty((b, self.max_new_tokens), dtype=np.int32)
+        steps = (C.c_int32 * b)()
+        unf = (C.c_int32 * b)()
+        _lib.check(self.lib.orc_read_slots(self._h, toks.ctypes.data_as(C.POINTER(C.c_int32)), steps, unf, _stream()), 'orc_read_slots')
+        return torch.from_numpy(toks).long(), list(steps), list(unf)
 
     def profile_enable(self, on=True):
         _lib.check(self.lib.orc_profile_enable(self._h, 1 if on else 0), 'orc_profile_enable')

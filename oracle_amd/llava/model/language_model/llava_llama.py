@@ -149,12 +149,14 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
     # ------------------------------------------------------------------ greedy generate
     @torch.no_grad()
     def generate(self, input_ids, images=None, do_sample=False, use_cache=True, max_new_tokens=20, stopping_criteria=None,
-                 vis_descriptor_embs=None, attention_mask=None, chunk=32, **kwargs):
+                 vis_descriptor_embs=None, attention_mask=None, chunk=16, limits=None, **kwargs):
         """Greedy search with the semantics of transformers' generate(do_sample=False) (A.6): returns
         LongTensor (B, L+n) = input_ids (placeholders intact) ++ new tokens; finished rows are filled with pad.
-        Decode steps run back to back on the device in chunks of `chunk` steps; stopping criteria are then replayed
-        on the host over the produced prefix, which gives the same stop step as checking after every token because
-        greedy tokens do not depend on how far the device ran ahead."""
+        Decode steps run back to back on the device in chunks of `chunk` steps (the host looks at the unfinished count
+        between chunks: at most chunk - 1 steps run past the stop, with finished rows frozen); stopping criteria are then
+        replayed on the host over the produced prefix, which gives the same stop step as checking after every token
+        because greedy tokens do not depend on how far the device ran ahead. limits: optional per-row length stops
+        (synthetic answer-length workloads; a row counts as finished after that many tokens)."""
         if do_sample:
             raise NotImplementedError('only greedy decoding (do_sample=False) is implemented, as ORacle uses')
         if max_new_tokens > self.engine.max_new_tokens:
@@ -182,6 +184,8 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
             max_new_tokens = self.engine.max_seq - t
         self.engine.prefill(embeds.to(torch.bfloat16).contiguous(), pos.to(device=self.device, dtype=torch.int32).contiguous(),
                             self._left_pad(mask))
+        if limits is not None:
+            self.engine.set_row_limits([min(int(x), max_new_tokens) for x in limits])
         while True:
             toks, done, n_unf, _ = self.engine.read_state()
             if n_unf == 0 or done >= max_new_tokens:
@@ -192,6 +196,8 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
         n = toks.shape[1]
         is_eos = toks == eos
         finished_at = torch.where(is_eos.any(-1), is_eos.long().argmax(-1) + 1, torch.full((b,), n + 1, device=toks.device))
+        if limits is not None:
+            finished_at = torch.minimum(finished_at, torch.as_tensor([int(x) for x in limits], device=toks.device))
         stop = min(int(finished_at.max()), n)
         if stopping_criteria:
             for s in range(1, stop):
@@ -200,3 +206,105 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
                     stop = s
                     break
         return torch.cat([input_ids, toks[:, :stop].to(input_ids.dtype)], dim=1)
+
+    # ------------------------------------------------------------------ continuous batching
+    @torch.no_grad()
+    def generate_stream(self, batches, max_new_tokens=20, n_slots=None, chunk=8, do_sample=False, use_cache=True,
+                        stopping_criteria=None):
+        """generate() over a stream of batches with slot refill. The reference decodes batch after
+        batch (scene_graph_prediction_model_oracle.py:251-260) and every batch runs as long as its longest answer; frames
+        are independent, so here a row of the running batch whose frame has finished (EOS / length stop) is refilled with
+        the next frame (single-row LLaMA prefill into that row's KV slot, orc_prefill_slot) while the others keep decoding.
+        Vision, pooling, projection and the splice still run per incoming batch, as in generate().
+
+        batches: iterable of dicts {'input_ids': (B, L) LongTensor, 'images': ..., 'vis_descriptor_embs': ... or None,
+        'limits': optional per-row length stops (synthetic workloads), 'stopping_criteria': optional, per batch}. Yields, in input order, what generate() returns
+        for each batch: (B, L + n) = input_ids ++ new tokens, rows that finished early filled with pad, n = the
+        longest row of that batch. Greedy tokens of a row do not depend on its neighbours (the decode GEMVs are
+        bit-invariant to the batch), so the results equal generate() batch by batch."""
+        if do_sample:
+            raise NotImplementedError('only greedy decoding (do_sample=False) is implemented, as ORacle uses')
+        eng = self.engine
+        if max_new_tokens > eng.max_new_tokens:
+            raise ValueError(f'max_new_tokens {max_new_tokens} exceeds the engine capacity {eng.max_new_tokens}')
+        n_slots = eng.max_batch if n_slots is None else n_slots
+        pad, eos = self.config.pad_token_id, self.config.eos_token_id
+        it = iter(batches)
+        info = {}                       # batch index -> {'ids', 'rows': {row: tokens}, 'n'}
+        queue = []                      # prepared rows waiting for a slot: (batch index, row, embeds (T, D), length stop)
+        slots = [None] * n_slots        # (batch index, row, length stop) of the frame decoding in each slot
+        next_in, next_out, exhausted = 0, 0, False
+        eng.stream_begin(n_slots)
+
+        def prepare():
+            nonlocal next_in, exhausted
+            try:
+                item = next(it)
+            except StopIteration:
+                exhausted = True
+                return
+            ids = item['input_ids']
+            images, vis = item.get('images'), item.get('vis_descriptor_embs')
+            limits = item.get('limits')
+            has_pad = pad is not None and bool((ids == pad).any()) and pad != eos
+            am = (ids != pad) if has_pad else torch.ones_like(ids, dtype=torch.bool)
+            inp = self.prepare_inputs_for_generation(ids, attention_mask=am, images=images, vis_descriptor_embs=vis, use_cache=use_cache)
+            _, _, mask, _, embeds, _ = self.prepare_inputs_labels_for_multimodal(inp['input_ids'], inp['position_ids'],
+                                                                                 inp['attention_mask'], None, None, images, vis)
+            if embeds is None:          # text-only prompt
+                embeds, mask = self.get_model().embed_tokens(ids), am
+            embeds = embeds.to(torch.bfloat16).contiguous()
+            m = mask.bool().cpu()
+            self._left_pad(m)           # refuses right-padded batches, as generate() does
+            counts = m.sum(-1).tolist()
+            t = embeds.shape[1]
+            for b in range(ids.shape[0]):
+                lim = max_new_tokens if limits is None else min(int(limits[b]), max_new_tokens)
+                if counts[b] + lim > eng.max_seq:
+                    if counts[b] >= eng.max_seq:
+                        raise ValueError(f'prompt ({counts[b]}) exceeds the KV capacity {eng.max_seq}')
+                    warnings.warn(f'prompt ({counts[b]}) + max_new_tokens ({lim}) exceeds the KV capacity {eng.max_seq}: '
+                                  f'generating at most {eng.max_seq - counts[b]} tokens')
+                    lim = eng.max_seq - counts[b]
+                queue.append((next_in, b, embeds[b, t - counts[b]:], lim))
+            info[next_in] = {'ids': ids, 'rows': {}, 'n': ids.shape[0], 'stopping': item.get('stopping_criteria', stopping_criteria)}
+            next_in += 1
+
+        def finished_batches():
+            nonlocal next_out
+            while next_out in info and len(info[next_out]['rows']) == info[next_out]['n']:
+                rec = info.pop(next_out)
+                ids = rec['ids']
+                n = max(len(t) for t in rec['rows'].values())
+                new = torch.full((ids.shape[0], n), pad if pad is not None else 0, dtype=ids.dtype)
+                for b, t in rec['rows'].items():
+                    new[b, :len(t)] = torch.as_tensor(t, dtype=ids.dtype)
+                out = torch.cat([ids, new.to(ids.device)], dim=1)
+                if rec['stopping']:        # replayed over the finished batch exactly as generate() does
+                    for s_ in range(1, n):
+                        if any(bool(c(out[:, :ids.shape[1] + s_], None)) for c in rec['stopping']):
+                            out = out[:, :ids.shape[1] + s_]
+                            break
+                next_out += 1
+                yield out
+
+        while True:
+            for s_ in range(n_slots):                                   # refill every free slot
+                if slots[s_] is None:
+                    if not queue and not exhausted:
+                        prepare()
+                    if queue:
+                        bi, row, emb, lim = queue.pop(0)
+                        eng.prefill_slot(s_, emb, lim)
+                        slots[s_] = (bi, row, lim)
+            if all(x is None for x in slots):
+                break
+            eng.decode_steps(chunk)
+            toks, steps, unf = eng.read_slots()
+            for s_ in range(n_slots):
+                if slots[s_] is not None and not unf[s_]:
+                    bi, row, lim = slots[s_]
+                    info[bi]['rows'][row] = toks[s_, :steps[s_]].tolist()
+                    slots[s_] = None
+            yield from finished_batches()
+        yield from finished_batches()

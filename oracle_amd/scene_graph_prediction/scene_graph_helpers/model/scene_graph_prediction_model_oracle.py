@@ -30,7 +30,7 @@ MEMORY_CHAR_LIMIT = 5000
 class OracleWrapper:
     def __init__(self, config, num_class, num_rel, weights_obj, weights_rel, relationNames, model_path,
                  model_base='liuhaotian/llava-v1.5-7b', load_8bit=False, load_4bit=False, mv_desc=False,
-                 device_preprocess=True, **engine_kw):
+                 device_preprocess=True, stream=True, **engine_kw):
         self.config = config
         self.mconfig = config['MODEL']
         self.n_object_types = 6
@@ -46,6 +46,7 @@ class OracleWrapper:
         self.model.config.tokenizer_padding_side = 'left'
         self.mv_desc = mv_desc
         self.device_preprocess, self._preproc = device_preprocess, None
+        self.stream = stream          # validate(): continuous batching across dataloader batches (identical outputs)
         self.temporal_online_prediction = config.get('temporality') == 'PRED'
         if self.temporal_online_prediction:
             print('Preparing temporality PRED')
@@ -110,7 +111,8 @@ class OracleWrapper:
         return t.to(self.model.device, dtype=torch.bfloat16)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, batch):
+    def _prepare(self, batch):
+        """Host side of forward() before generate(): views -> image tensor, prompts -> left-padded ids, stopping criterion."""
         images, prompt_texts, vis_desc = [], [], []
         conv = None
         for elem in batch:
@@ -132,10 +134,11 @@ class OracleWrapper:
             image_tensor = torch.cat(images)
         stop_str = conv.sep if conv.sep_style != SeparatorStyle.TWO else conv.sep2
         stopping = KeywordsStoppingCriteria([stop_str], self.tokenizer, input_ids)
-        with torch.inference_mode():
-            output_ids = self.model.generate(input_ids, images=image_tensor, do_sample=False, use_cache=True, max_new_tokens=300,
-                                             stopping_criteria=[stopping],
-                                             vis_descriptor_embs=vis_desc if self._use_vis_desc() else None)
+        return {'input_ids': input_ids, 'images': image_tensor, 'stopping_criteria': [stopping],
+                'vis_descriptor_embs': vis_desc if self._use_vis_desc() else None}
+
+    def _finish(self, batch, input_ids, output_ids):
+        """Host side of forward() after generate(): token ids -> strings (+ symbolic back-map)."""
         new = output_ids[:, input_ids.shape[1]:]
         if len(batch) == 1:
             outputs = [self.tokenizer.decode(new[0]).strip()]
@@ -144,6 +147,31 @@ class OracleWrapper:
         if self._is_symbolic() or self.config['USE_VIS_DESC']:
             outputs = [self.symbols_to_names(o) for o in outputs]
         return outputs
+
+    def forward(self, batch):
+        p = self._prepare(batch)
+        with torch.inference_mode():
+            output_ids = self.model.generate(p['input_ids'], images=p['images'], do_sample=False, use_cache=True, max_new_tokens=300,
+                                             stopping_criteria=p['stopping_criteria'], vis_descriptor_embs=p['vis_descriptor_embs'])
+        return self._finish(batch, p['input_ids'], output_ids)
+
+    def forward_stream(self, dataloader):
+        """forward() over a whole dataloader with slot refill (LlavaLlamaForCausalLM.generate_stream): a row whose frame has
+        finished is given the next frame instead of idling until the longest answer of its batch ends. Yields
+        (batch, outputs) in dataloader order with the outputs forward(batch) returns. Not for the online-temporal variant
+        (frame t needs the predictions of frames < t)."""
+        assert not self.temporal_online_prediction
+        pending = []
+
+        def items():
+            for batch in dataloader:
+                p = self._prepare(batch)
+                pending.append((batch, p['input_ids']))
+                yield p
+        with torch.inference_mode():
+            for output_ids in self.model.generate_stream(items(), max_new_tokens=300):
+                batch, input_ids = pending.pop(0)
+                yield batch, self._finish(batch, input_ids, output_ids)
 
     @staticmethod
     def symbols_to_names(output):
@@ -222,13 +250,25 @@ class OracleWrapper:
         elif isinstance(limit_val_batches, float):
             limit = int(limit_val_batches * len(dataloader))
         none_id = self.relation_names_lower_case.index('none')
-        for batch in dataloader:
-            if limit is not None:
-                if limit <= 0:
-                    break
-                limit -= 1
+
+        def limited():
+            left = limit
+            for batch in dataloader:
+                if left is not None:
+                    if left <= 0:
+                        return
+                    left -= 1
+                yield batch
+
+        def run():
+            if self.stream and not self.temporal_online_prediction and hasattr(self.model, 'generate_stream'):
+                yield from self.forward_stream(limited())
+            else:
+                for batch in limited():
+                    yield batch, self.forward(batch)
+
+        for batch, outputs in run():
             assert len(batch) == 1 or not self.temporal_online_prediction
-            outputs = self.forward(batch)
             for elem, output in zip(batch, outputs):
                 timepoint = int(elem['scan_id'].split('_')[1])
                 take_idx = elem['take_idx']

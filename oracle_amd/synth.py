@@ -161,3 +161,48 @@ def synth_images(n_frames, views, d: Dims, seed=1234, dtype=torch.bfloat16):
         frames.append(torch.from_numpy(np.clip(x, -1.8, 2.2)))
     x = torch.stack(frames).to(dtype)
     return x[:, 0] if views == 1 else x
+
+
+SELECT_DIRS = 2          # image-dependent directions; 2 * SELECT_DIRS candidate chains
+SELECT_CHAIN_LEN = 24    # tokens reserved per candidate chain inside [CHAIN_BASE, ...)
+
+
+def select_chain_layout(n_dirs=SELECT_DIRS, base=CHAIN_BASE, stride=SELECT_CHAIN_LEN):
+    """[(first token, last token)] of the 2*n_dirs candidate chains; chain k emits 6 + 3k tokens, then EOS."""
+    return [(base + k * stride, base + k * stride + 5 + 3 * k) for k in range(2 * n_dirs)]
+
+
+def install_select_chains(state, d: Dims, center=None, n_dirs=SELECT_DIRS, g_sel=60.0, logit=60.0, boost=12.0, seed=77):
+    """Greedy decoding whose answer is SELECTED BY THE IMAGE: with the <image> placeholder as the last
+    prompt token, the final hidden state of the prefill is the LLaMA image of the last pooled + projected image-token row,
+    i.e. ~70 % of it varies from frame to frame. lm_head rows of the 2*n_dirs chain-start tokens get +-g_sel along n_dirs
+    fixed random unit directions r_j of that state, so the FIRST answer token is argmax_k (+-<h, r_j>): a function of
+    the vision tower, the pooler (mask, positions), the projector, the splice and the LLaMA layers, with a top-2 margin
+    that is a continuous random variable (moderately peaked: some frames land within bf16 noise, most do not). The
+    decode then continues along the selected chain (token v -> v+1 by a wide margin, as install_chain) for 6 + 3k tokens
+    and ends with EOS, so rows of a batch finish at different steps. Chain-token embeddings are made orthogonal to the
+    r_j, and their boost keeps the selection rows quiet at the later positions. `center` (d_model floats) is the mean of
+    that hidden state over a few calibration frames (computed by the test infrastructure and stored with the golden
+    vectors); the r_j are made orthogonal to it so the frame-independent part does not decide the argmax."""
+    import math
+    emb = state['model.embed_tokens.weight'].float()
+    w = state['lm_head.weight'].float()
+    dm = d.d_model
+    r = torch.from_numpy(_philox_normal(seed, 'select_dirs', (n_dirs, dm)))
+    if center is not None:
+        c = torch.as_tensor(center, dtype=torch.float32)
+        c = c / c.norm()
+        r = r - (r @ c)[:, None] * c
+    r = torch.linalg.qr(r.T).Q.T.contiguous()                          # orthonormal rows (still orthogonal to center)
+    g = logit / math.sqrt(dm)
+    for k, (lo, hi) in enumerate(select_chain_layout(n_dirs)):
+        u = emb[lo:hi + 1]
+        u = u - (u @ r.T) @ r                                           # orthogonal to the selection directions
+        u = u / u.norm(dim=-1, keepdim=True)
+        emb[lo:hi + 1] = u * (boost * math.sqrt(dm))
+        w[lo + 1:hi + 1] += g * u[:-1]                                  # v -> v + 1 inside the chain
+        w[2] += g * u[-1]                                               # last token of the chain -> EOS
+        w[lo] += (g_sel if k % 2 == 0 else -g_sel) * r[k // 2]          # chain start: +- <h, r_j>
+    state['model.embed_tokens.weight'] = emb.to(state['model.embed_tokens.weight'].dtype)
+    state['lm_head.weight'] = w.to(state['lm_head.weight'].dtype)
+    return state

@@ -129,3 +129,23 @@ def test_full_width_llama_and_full_depth_clip():
     with torch.inference_mode():
         vt = cr.vision_tower(stv, dv, synth_images(1, 3, dv, seed=4321)[0])
     _close(vt, gv, 'vt', 19, 23, 1e-2)
+
+
+def test_restatement_reproduces_image_selected_answers():
+    """First batch (16 frames) of the image-selected population (tests/golden/select_tiny_bfloat16.npz, generated by the
+    real reference): the CPU restatement returns the same tokens, and the selection really varies with the image."""
+    import numpy as np
+    from oracle import cpu_ref as cr
+    from oracle_amd.dims import TINY
+    from oracle_amd.synth import install_select_chains, select_chain_layout, synth_images, synth_state
+    g = np.load(os.path.join(GOLDEN, 'select_tiny_bfloat16.npz'))
+    st = install_select_chains(synth_state(TINY, seed=0), TINY, center=torch.from_numpy(g['center']))
+    ids = torch.from_numpy(g['last.ids'])[:16]
+    ids = ids[:, int((ids != 0).any(0).long().argmax()):]
+    imgs = synth_images(16, 3, TINY, seed=7000)
+    out = cr.greedy_generate(st, TINY, ids, imgs, max_new_tokens=24)[:, ids.shape[1]:]
+    gold = torch.from_numpy(g['last.generated'])[:16, :out.shape[1]]
+    assert torch.equal(out, gold)
+    starts = {lo for lo, _ in select_chain_layout()}
+    firsts = set(torch.from_numpy(g['last.generated'])[:, 0].tolist())
+    assert firsts <= starts and len(firsts) == len(starts)

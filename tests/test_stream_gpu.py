@@ -1,0 +1,82 @@
+"""GPU: continuous batching (generate_stream / orc_stream_begin + orc_prefill_slot + orc_read_slots): a stream of ragged
+batches through 4 row slots with refill must return, batch by batch, exactly what generate() returns for that batch alone
+(and what the CPU oracle returns): per-row cached lengths, frozen finished rows, per-row length stops."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def chain():
+    from oracle_amd.dims import TINY
+    from oracle_amd.engine import Engine
+    from oracle_amd.llava.model.language_model.llava_llama import LlavaConfig, LlavaLlamaForCausalLM
+    from oracle_amd.synth import install_chain, synth_state
+    st = install_chain(synth_state(TINY, seed=0), TINY)
+    eng = Engine(TINY, max_batch=8, max_seq=700, max_images=32, max_new_tokens=48)
+    eng.load_state(st)
+    model = LlavaLlamaForCausalLM(LlavaConfig(TINY, tokenizer_padding_side='left'), eng)
+    yield st, eng, model
+    eng.close()
+
+
+def _batches(sizes, seed):
+    import random
+    from oracle_amd.dims import TINY
+    from oracle_amd.synth import CHAIN_BASE, CHAIN_LEN, synth_images
+    rng = random.Random(seed)
+    e = CHAIN_BASE + CHAIN_LEN
+    out = []
+    for k, b in enumerate(sizes):
+        rows = []
+        for i in range(b):
+            pre = [rng.randrange(3, 1000) for _ in range(rng.randint(0, 9))]
+            post = [rng.randrange(3, 1000) for _ in range(rng.randint(0, 6))]
+            rows.append([1] + pre + [-200] + post + [e - rng.randint(2, 30)])      # 2..30 chain tokens, then EOS
+        L = max(len(r) for r in rows)
+        ids = torch.tensor([[0] * (L - len(r)) + r for r in rows])
+        out.append({'input_ids': ids.cuda(), 'images': synth_images(b, 3, TINY, seed=300 + 17 * k + seed).cuda()})
+    return out
+
+
+@pytest.mark.parametrize('n_slots,chunk', [(4, 4), (8, 8), (1, 3)])
+def test_stream_equals_generate_batch_by_batch(chain, n_slots, chunk):
+    from oracle import cpu_ref as cr
+    from oracle_amd.dims import TINY
+    st, eng, model = chain
+    items = _batches([3, 8, 1, 5, 2, 8], seed=n_slots)
+    outs = [o.cpu() for o in model.generate_stream(iter(items), max_new_tokens=40, n_slots=n_slots, chunk=chunk)]
+    assert len(outs) == len(items)
+    for k, (item, out) in enumerate(zip(items, outs)):
+        ref = model.generate(item['input_ids'], images=item['images'], do_sample=False, use_cache=True, max_new_tokens=40).cpu()
+        assert torch.equal(out, ref), (k, out[:, item['input_ids'].shape[1]:], ref[:, item['input_ids'].shape[1]:])
+    for k in (0, 3):                                                              # and the CPU oracle
+        ref = cr.greedy_generate(st, TINY, items[k]['input_ids'].cpu(), items[k]['images'].cpu(), max_new_tokens=40)
+        assert torch.equal(outs[k], ref)
+
+
+def test_stream_length_stops_and_capacity(chain):
+    from oracle_amd import _lib
+    st, eng, model = chain
+    items = _batches([4, 4], seed=9)
+    items[0]['limits'] = [1, 3, 40, 2]
+    outs = [o.cpu() for o in model.generate_stream(iter(items), max_new_tokens=40, n_slots=3, chunk=2)]
+    full = model.generate(items[0]['input_ids'], images=items[0]['images'], max_new_tokens=40).cpu()
+    L = items[0]['input_ids'].shape[1]
+    for b, lim in enumerate(items[0]['limits']):
+        n = min(lim, int((full[b, L:] != 0).sum()))                               # the stop, or the row's own EOS if earlier
+        assert torch.equal(outs[0][b, L:L + n], full[b, L:L + n])
+        assert bool((outs[0][b, L + n:] == 0).all())
+    assert torch.equal(outs[1], model.generate(items[1]['input_ids'], images=items[1]['images'], max_new_tokens=40).cpu())
+    # the C ABI refuses a slot outside the running batch, a stop beyond the token buffer, a prompt that cannot fit
+    eng.stream_begin(2)
+    emb = torch.zeros(10, 512, dtype=torch.bfloat16, device='cuda')
+    with pytest.raises(_lib.OracleHipError, match='slot outside'):
+        eng.prefill_slot(2, emb, 4)
+    with pytest.raises(_lib.OracleHipError, match='length stop'):
+        eng.prefill_slot(0, emb, 49)
+    with pytest.raises(_lib.OracleHipError, match='exceeds max_seq'):
+        eng.prefill_slot(0, torch.zeros(690, 512, dtype=torch.bfloat16, device='cuda'), 20)
+    with pytest.raises(_lib.OracleHipError, match='teacher forcing'):
+        eng.decode_step(torch.tensor([5, 5]).cuda())
