@@ -175,7 +175,8 @@ def ragged_lengths(n, seed, cap):
 def ragged_runs(model, input_ids, images, batch, n_batches, rank):
     """The same workload with the 4D-OR answer-length distribution instead of a uniform 150 tokens:
     (a) batch by batch through generate() -- every batch decodes until its longest answer ends (the reference's loop);
-    (b) generate_stream() -- a finished row is refilled with the next frame. Same frames, same per-frame length stops."""
+    (b) generate_stream() -- the next batch is prefilled ahead into spare KV slots and a finished row continues with a
+    waiting frame at once. Same frames, same per-frame length stops, same decode width (batch rows)."""
     import torch
     lens, d = ragged_lengths(batch * n_batches, 4242 + rank, 300)
     items = [{'input_ids': input_ids, 'images': images, 'limits': lens[i * batch:(i + 1) * batch]} for i in range(n_batches)]
@@ -190,7 +191,7 @@ def ragged_runs(model, input_ids, images, batch, n_batches, rank):
                 res = [model.generate(it['input_ids'], images=it['images'], do_sample=False, use_cache=True, max_new_tokens=300,
                                       limits=it['limits'], chunk=8) for it in items]
             else:
-                res = list(model.generate_stream(iter(items), max_new_tokens=300, n_slots=batch, chunk=8))
+                res = list(model.generate_stream(iter(items), max_new_tokens=300, n_rows=batch, chunk=8))
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
         L = input_ids.shape[1]
@@ -257,7 +258,7 @@ def main():
     ap.add_argument('--lengths', default='both', choices=['uniform', 'both'],
                     help="'both' (default): after the uniform-length headline also run the 4D-OR answer-length distribution "
                          "(extra.ragged: batch-by-batch vs slot refill); 'uniform': headline only")
-    ap.add_argument('--ragged-batches', type=int, default=4)
+    ap.add_argument('--ragged-batches', type=int, default=8)
     ap.add_argument('--dry-run', action='store_true',
                     help='launcher / rendezvous / gather / max-over-ranks plumbing only (no GPU, no engine): CPU test of the N>1 path')
     a = ap.parse_args()
@@ -300,7 +301,9 @@ def main():
     probe_ids, _ = build_inputs(tok, 1, 1, dims, 'cpu', a.prompt)
     T = probe_ids.shape[1] - 1 + 576
     cap_new = max(a.new_tokens, 300 if a.lengths == 'both' else 16)   # the ragged leg decodes up to the reference's 300
-    eng = Engine(dims, max_batch=a.batch, max_seq=T + cap_new + 8, max_images=a.batch * a.views,
+    # KV-cache slots: the ragged leg decodes a.batch rows and prefills the next batch ahead into as many spare slots
+    n_slots = min(16, 2 * a.batch) if a.lengths == 'both' else a.batch
+    eng = Engine(dims, max_batch=n_slots, max_seq=T + cap_new + 8, max_images=a.batch * a.views,
                  max_new_tokens=cap_new, pad_token_id=0, eos_token_id=-1, device=dev)
     eng.load_state(state)
     del state

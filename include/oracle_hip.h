@@ -121,16 +121,25 @@ int orc_read_state(orc_engine* e, int32_t* tokens_host, int32_t* steps_host, int
 int orc_set_row_limits(orc_engine* e, const int32_t* limits_host, int n, void* stream);
 
 /* Continuous batching over the reference's outer loop (`for batch in dataloader: self.forward(batch)`,
- * scene_graph_prediction_model_oracle.py:251-260): frames are independent, so a row slot whose frame has finished (EOS or
- * its length stop) is refilled with the next frame while the other rows keep decoding. Every row keeps its own cached
- * length, step counter and length stop on the device; a finished row freezes (no cache growth, no cache reads).
- * orc_stream_begin: n_slots empty rows. orc_prefill_slot: LlavaLlamaForCausalLM.forward step 0 for ONE unpadded row
- * (embeds (T, d_model), positions 0..T-1) into row `slot`: fills that row's KV cache, resets its greedy state with the
- * length stop max_new (<= max_new_tokens; T + max_new <= max_seq), samples its first token. orc_decode_steps then advances
- * every unfinished row. orc_read_slots: synchronises and reads tokens (n_slots * max_new_tokens, pad-filled), tokens
- * emitted per row, unfinished flags. orc_prefill (a whole left-padded batch) ends the stream. */
-int orc_stream_begin(orc_engine* e, int n_slots, void* stream);
-int orc_prefill_slot(orc_engine* e, int slot, const void* embeds, int T, int max_new, float* logits_out, void* stream);
+ * scene_graph_prediction_model_oracle.py:251-260): frames are independent, so a decode row whose frame has finished (EOS or
+ * its length stop) takes over the next frame while the other rows keep decoding. The engine has max_batch KV-cache SLOTS,
+ * each with its own greedy state on the device (cached length, left pad, step counter, length stop, unfinished flag,
+ * next token, token buffer); a decode launch runs over n_rows ROWS (n_rows <= max_batch), each attached to one slot.
+ *   orc_stream_begin   n_rows decode rows, none attached.
+ *   orc_prefill_slots  LlavaLlamaForCausalLM.forward step 0 (llava_llama.py:54-100) for n left-padded rows (embeds
+ *                      (n, T, d_model), position_ids (n*T) device, left_pad_host[n]) into the UNATTACHED slots
+ *                      slots_host[n]: fills their KV cache, resets their state with the length stops limits_host[n]
+ *                      (<= max_new_tokens, T + limit <= max_seq), samples each row's first token. Batched like orc_prefill,
+ *                      so a whole incoming batch can be prefilled AHEAD into free slots while other frames decode.
+ *   orc_stream_attach  host-only: decode row `row` continues with slot `slot` (-1 detaches) from the next decode step on.
+ *   orc_decode_steps   advances every attached, unfinished row; a finished row freezes (no cache growth, no cache reads).
+ *   orc_read_slots     synchronises and reads, for all max_batch slots: tokens (max_batch * max_new_tokens, pad-filled),
+ *                      tokens emitted, unfinished flags.
+ * orc_prefill (a whole batch into slots 0..B-1, rows attached 1:1) ends the stream. */
+int orc_stream_begin(orc_engine* e, int n_rows, void* stream);
+int orc_prefill_slots(orc_engine* e, const int32_t* slots_host, int n, const void* embeds, const int32_t* position_ids,
+                      const int32_t* left_pad_host, const int32_t* limits_host, int T, float* logits_out, void* stream);
+int orc_stream_attach(orc_engine* e, int row, int slot);
 int orc_read_slots(orc_engine* e, int32_t* tokens_host, int32_t* row_steps_host, int32_t* unfinished_host, void* stream);
 
 /* test / profiling hooks for single kernels (same kernels the engine runs). */

@@ -47,7 +47,8 @@ SYMBOLS = {
     'orc_read_state': (_I, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P]),
     'orc_set_row_limits': (_I, [_P, C.POINTER(C.c_int32), _I, _P]),
     'orc_stream_begin': (_I, [_P, _I, _P]),
-    'orc_prefill_slot': (_I, [_P, _I, _P, _I, _I, _P, _P]),
+    'orc_prefill_slots': (_I, [_P, C.POINTER(C.c_int32), _I, _P, _P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _P, _P]),
+    'orc_stream_attach': (_I, [_P, _I, _I]),
     'orc_read_slots': (_I, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P]),
     'orc_test_gemm': (_I, [_P, _I, _I, _P, _I, _P, _P, _I, _I, _P, _P]),
     'orc_test_rmsnorm': (_I, [_P, _P, _I, _I, _F, _P, _P]),

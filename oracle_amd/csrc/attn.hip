@@ -89,8 +89,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a, int order) {
     for (int i = 0; i < HD / 16; ++i) o[qb][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
 
-  const bf16_t* kbase = a.K + (size_t)b * a.k_bs + (size_t)h * a.k_hs;
-  const bf16_t* vbase = a.V + (size_t)b * a.v_bs + (size_t)h * a.v_hs;
+  const int kvb = a.kv_map_on ? a.kv_map.slot[b] : b;        // KV-cache slot of this batch row (prefill into arbitrary slots)
+  const bf16_t* kbase = a.K + (size_t)kvb * a.k_bs + (size_t)h * a.k_hs;
+  const bf16_t* vbase = a.V + (size_t)kvb * a.v_bs + (size_t)h * a.v_hs;
   // DMA addressing: lane p of round r fills 16-B slot r*256 + p of the image, i.e. key r*(256/CH) + p/CH, chunk p%CH.
   // The per-lane part (key row inside the round, swizzled source chunk) is loop-invariant and the per-round / per-tile
   // part is wave-uniform, so a tile costs no vector address arithmetic; only the tile that crosses Sk clamps per lane.
@@ -252,9 +253,10 @@ __global__ __launch_bounds__(WAVES * 64) void decode_attn_kernel(DecodeAttnArgs 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int kq = lane >> 4, c = lane & 15;
   const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z, nsplit = gridDim.z;
-  const int len = a.cur_len[b];
-  const int kb = a.kbeg[b];
-  if (a.unfinished && !a.unfinished[b]) {   // finished row (its tokens are pad from here on): no cache read at all
+  const int sl = a.map.slot[b];
+  const int len = sl < 0 ? 1 : a.cur_len[sl];
+  const int kb = sl < 0 ? 0 : a.kbeg[sl];
+  if (sl < 0 || (a.unfinished && !a.unfinished[sl])) {   // inactive or finished row (its tokens are pad): no cache read at all
     if (tid < 128) {
       if (nsplit == 1) {
         a.O[a.o_xf ? xf_off(b, h * 128 + tid) : (size_t)b * a.o_bs + h * 128 + tid] = 0;
@@ -277,8 +279,8 @@ __global__ __launch_bounds__(WAVES * 64) void decode_attn_kernel(DecodeAttnArgs 
 #pragma unroll
     for (int j = 0; j < 4; ++j) { q[2 * j] = lo_bf(qv[j]); q[2 * j + 1] = hi_bf(qv[j]); }
   }
-  const bf16_t* kc = a.Kc + (size_t)b * a.c_bs + (size_t)h * a.c_hs + c * 8;
-  const bf16_t* vc = a.Vc + (size_t)b * a.c_bs + (size_t)h * a.c_hs + c * 8;
+  const bf16_t* kc = a.Kc + (size_t)sl * a.c_bs + (size_t)h * a.c_hs + c * 8;
+  const bf16_t* vc = a.Vc + (size_t)sl * a.c_bs + (size_t)h * a.c_hs + c * 8;
 
   float m = -INFINITY, l = 0.f, acc[8];
 #pragma unroll

@@ -103,9 +103,9 @@ struct orc_engine {
   bf16_t *d_h = nullptr, *d_xn = nullptr, *d_qkv = nullptr, *d_att = nullptr, *d_mlp = nullptr;   // decode (<=16 rows)
   int *dev_ints = nullptr;   // [0]=step [2]=n_unfinished, then per-row arrays of 16 (DI_* offsets), then the token buffer
   int *d_step, *d_nunf, *d_unf, *d_next, *d_argmax, *d_kbeg, *d_kend, *d_rowoff, *d_rowvalid, *d_curlen, *d_rowstep, *d_limit, *d_tokens;
-  int* d_iota = nullptr;     // 0, 1, 2, ... max_seq-1: position ids of an unpadded row (orc_prefill_slot)
-  bool stream_mode = false;  // continuous batching (orc_stream_begin): rows are (re)filled one at a time
-  int slot_T[16] = {0};
+  int* d_pfkbeg = nullptr;   // [16] left pad of the rows of the prefill being launched (attention reads it per launch row)
+  bool stream_mode = false;  // continuous batching (orc_stream_begin): decode rows are re-pointed at slots prefilled ahead
+  RowMap row_map;            // decode row -> slot (host copy; goes to the kernels by value)
   int* h_pinned = nullptr;   // pinned host staging (small int arrays)
   int cur_batch = 0, cur_T = 0;
   int steps_issued = 0;   // decode steps enqueued since the last prefill (host-side mirror of the device cur_len - T)
@@ -477,12 +477,8 @@ extern "C" int orc_engine_finalize(orc_engine* e) {
     e->d_kend = di + DI_KEND; e->d_rowoff = di + DI_ROWOFF; e->d_rowvalid = di + DI_ROWVALID;
     e->d_curlen = di + DI_CURLEN; e->d_rowstep = di + DI_ROWSTEP; e->d_limit = di + DI_LIMIT;
     e->d_tokens = di + DI_TOKENS;
-    {
-      std::vector<int> iota(c.max_seq);
-      for (int i = 0; i < c.max_seq; ++i) iota[i] = i;
-      ORCCHK(e->alloc((void**)&e->d_iota, (size_t)c.max_seq * 4));
-      HIPCHK(hipMemcpy(e->d_iota, iota.data(), (size_t)c.max_seq * 4, hipMemcpyHostToDevice));
-    }
+    e->d_pfkbeg = di + DI_KEND;   // (the pooler's key-end array is not used by a LLaMA prefill)
+    e->row_map = identity_map();
     HIPCHK(hipHostMalloc((void**)&e->h_pinned, 4096, hipHostMallocDefault));
   }
   HIPCHK(hipDeviceSynchronize());
@@ -635,6 +631,7 @@ static int gemv_ex(orc_engine* e, const bf16_t* X, int ldx, const Packed& W, con
   GemvArgs a = {};
   a.x_xf = x_xf; a.c_xf = c_xf; a.ev_start = ev_start; a.ev_stop = ev_stop;
   a.ssq_in = ssq_in; a.n_part = c.d_model / 16; a.norm_d = c.d_model; a.norm_eps = c.rms_eps; a.C_xf = C_xf;
+  a.map = e->row_map;
   a.X = X; a.ldx = ldx; a.Wp = W.p; a.bias = nullptr; a.R = R; a.ldr = ldc; a.C = C; a.ldc = ldc;
   a.M = M; a.N = W.N; a.K = W.K; a.Nvalid = (epi == EPI_SWIGLU) ? W.Nvalid / 2 : W.Nvalid;
   a.H = c.n_heads; a.kbeg = e->d_kbeg; a.cur_len = e->d_curlen; a.cos_tab = e->cos_tab; a.sin_tab = e->sin_tab;
@@ -646,29 +643,30 @@ static int gemv_ex(orc_engine* e, const bf16_t* X, int ldx, const Packed& W, con
 }
 
 // prefill: tiled MFMA GEMMs + flash attention over all B*T positions
-// row0: first row slot of the KV cache / per-row state the B rows go to (0 for a batch prefill)
+// pm: batch row -> KV-cache slot the row is prefilled into
 static int llama_prefill_layers(orc_engine* e, bf16_t* h, bf16_t* xn, bf16_t* qkv, bf16_t* att, bf16_t* mlp, int B, int T,
-                                const int32_t* pos, hipStream_t s, int row0 = 0) {
+                                const int32_t* pos, hipStream_t s, const RowMap& pm) {
   const orc_config& c = e->c;
   const int d = c.d_model, M = B * T;
   for (int i = 0; i < c.n_layers; ++i) {
     const LlamaLayer& L = e->llama[i];
-    bf16_t* kc = e->kcache + (size_t)i * e->kv_layer_elems + (size_t)row0 * e->c_bs;
-    bf16_t* vc = e->vcache + (size_t)i * e->kv_layer_elems + (size_t)row0 * e->c_bs;
+    bf16_t* kc = e->kcache + (size_t)i * e->kv_layer_elems;
+    bf16_t* vc = e->vcache + (size_t)i * e->kv_layer_elems;
     HIPCHK(launch_rmsnorm(h, d, L.ln_in, xn, d, M, d, c.rms_eps, s));
     ORCCHK(gemm(xn, d, L.qkv, nullptr, nullptr, 0, qkv, 3 * d, M, EPI_NONE, s, false));
     RopeArgs r;
-    r.qkv = qkv; r.B = B; r.T = T; r.H = c.n_heads; r.pos = pos; r.kbeg = e->d_kbeg + row0; r.cur_len = e->d_curlen + row0;
+    r.qkv = qkv; r.B = B; r.T = T; r.H = c.n_heads; r.pos = pos; r.kbeg = e->d_kbeg; r.cur_len = e->d_curlen;
     r.cos_tab = e->cos_tab; r.sin_tab = e->sin_tab; r.maxpos = e->maxpos; r.Kc = kc; r.Vc = vc; r.c_bs = e->c_bs; r.c_hs = e->c_hs;
-    r.t0 = 0;
+    r.t0 = 0; r.map = pm;
     HIPCHK(launch_rope_kv(r, s));
     AttnArgs a;
     a.Q = qkv; a.q_bs = (long)T * 3 * d; a.q_hs = 128; a.q_ts = 3 * d;
     a.K = kc; a.k_bs = e->c_bs; a.k_hs = e->c_hs; a.k_ts = 128;
     a.V = vc; a.v_bs = e->c_bs; a.v_hs = e->c_hs; a.v_ts = 128;
     a.O = att; a.o_bs = (long)T * d; a.o_hs = 128; a.o_ts = d;
-    a.B = B; a.H = c.n_heads; a.Sq = T; a.Sk = T; a.kbeg = e->d_kbeg + row0; a.kend = nullptr; a.causal = 1; a.q_off = 0;
+    a.B = B; a.H = c.n_heads; a.Sq = T; a.Sk = T; a.kbeg = e->d_pfkbeg; a.kend = nullptr; a.causal = 1; a.q_off = 0;
     a.scale = 0.08838834764831845f;
+    a.kv_map_on = 1; a.kv_map = pm;
     HIPCHK(launch_attention(a, 128, s));
     ORCCHK(gemm(att, d, L.o, nullptr, h, d, h, d, M, EPI_RESIDUAL, s, false));
     HIPCHK(launch_rmsnorm(h, d, L.ln_post, xn, d, M, d, c.rms_eps, s));
@@ -702,6 +700,7 @@ static int llama_decode_layers(orc_engine* e, int B, hipStream_t s, bool skip_fi
     a.Q = q; a.q_bs = d; a.Kc = kc; a.Vc = vc; a.c_bs = e->c_bs; a.c_hs = e->c_hs; a.O = att; a.o_bs = d;
     a.part = e->w_part; a.kbeg = e->d_kbeg; a.cur_len = e->d_curlen; a.B = B; a.H = c.n_heads;
     a.unfinished = skip_finished ? e->d_unf : nullptr;
+    a.map = e->row_map;
     a.scale = 0.08838834764831845f;
     HIPCHK(launch_decode_attention(a, s));
     ORCCHK(gemv_ex(e, att, d, L.o, h, h, d, B, EPI_RESIDUAL, s, nullptr, nullptr, e->d_ssq, 1, 0, nullptr, nullptr, nullptr, hxf));
@@ -716,10 +715,10 @@ static int llama_decode_layers(orc_engine* e, int B, hipStream_t s, bool skip_fi
   return 0;
 }
 
-// final RMSNorm + lm_head + greedy sampling of B rows that live in state rows row0 .. row0 + B - 1.
-// from_decode: hrows = d_h with fresh partials in d_ssq (row0 = 0, B = the whole batch).
+// final RMSNorm + lm_head + greedy sampling of B rows; row i owns the state of slot sm.slot[i].
+// from_decode: hrows = d_h with fresh partials in d_ssq and the raw rows in d_hxf (the decode rows, sm = the decode map).
 static int head_and_sample(orc_engine* e, const bf16_t* hrows, int ldh, int B, float* logits_out, bool from_decode, hipStream_t s,
-                           int row0 = 0, bool freeze = true) {
+                           const RowMap& sm, bool freeze = true) {
   const orc_config& c = e->c;
   if (from_decode) {   // final RMSNorm folded into the lm_head projection (raw rows in d_hxf, partials in d_ssq)
     ORCCHK(gemv_ex(e, e->d_hxf, c.d_model, e->lm_head_dec, nullptr, e->w_logits, c.vocab, B, EPI_F32, s, nullptr, nullptr, nullptr, 1, 0,
@@ -731,7 +730,7 @@ static int head_and_sample(orc_engine* e, const bf16_t* hrows, int ldh, int B, f
   if (logits_out)
     HIPCHK(hipMemcpyAsync(logits_out, e->w_logits, (size_t)B * c.vocab * 4, hipMemcpyDeviceToDevice, s));
   SampleArgs a;
-  a.logits = e->w_logits; a.vocab = c.vocab; a.B = B; a.row0 = row0; a.n_rows = e->cur_batch;
+  a.logits = e->w_logits; a.vocab = c.vocab; a.B = B; a.map = sm; a.count = e->row_map; a.n_count = e->cur_batch;
   a.unfinished = e->d_unf; a.next_ids = e->d_next;
   a.raw_argmax = e->d_argmax; a.out_tokens = e->d_tokens; a.out_ld = c.max_new_tokens; a.row_step = e->d_rowstep;
   a.cur_len = e->d_curlen; a.limit = e->d_limit; a.step = e->d_step; a.n_unfinished = e->d_nunf;
@@ -740,47 +739,57 @@ static int head_and_sample(orc_engine* e, const bf16_t* hrows, int ldh, int B, f
   return 0;
 }
 
-// uploads the per-row greedy state of rows [row0, row0 + n): unfinished = 1, kbeg, cur_len = T (keys cached after the
-// prefill; sampling advances it to T + 1 for the first decode step), step 0, the length stop; pad-fills their token rows
-static int reset_rows(orc_engine* e, int row0, int n, const int* kbeg_host, int T, int limit, hipStream_t s) {
-  int* hp = e->h_pinned;
-  HIPCHK(hipStreamSynchronize(s));   // pinned staging reuse
-  for (int i = 0; i < n; ++i) {
-    hp[i] = 1; hp[16 + i] = kbeg_host ? kbeg_host[i] : 0; hp[32 + i] = T; hp[48 + i] = 0; hp[64 + i] = limit;
+// LlavaLlamaForCausalLM.forward step 0 for k left-padded rows into the KV-cache slots slots[0..k): resets those slots'
+// greedy state (one small launch, no host staging), runs the 32 layers over all k * T positions, samples each row's first token
+static int prefill_into_slots(orc_engine* e, const int* slots, int k, const void* embeds, const int32_t* position_ids,
+                              const int32_t* left_pad, const int32_t* limits, int T, float* logits_out, hipStream_t s, const char* who) {
+  const orc_config& c = e->c;
+  if (k < 1 || k > c.max_batch) return fail(who, "row count outside 1..max_batch");
+  if (T < 1 || T >= c.max_seq) return fail(who, "prompt length exceeds max_seq");
+  if ((long)k * T > e->ws_rows) return fail(who, "rows*T exceeds workspace");
+  SlotInitArgs in = {};
+  RowMap pm;
+  for (int i = 0; i < 16; ++i) pm.slot[i] = -1;
+  for (int i = 0; i < k; ++i) {
+    if (slots[i] < 0 || slots[i] >= c.max_batch) return fail(who, "slot outside 0..max_batch-1");
+    for (int j = 0; j < i; ++j)
+      if (slots[j] == slots[i]) return fail(who, "a slot is named twice");
+    if (left_pad[i] < 0 || left_pad[i] >= T) return fail(who, "left_pad outside 0..T-1");
+    const int lim = limits ? limits[i] : c.max_new_tokens;
+    if (lim < 1 || lim > c.max_new_tokens) return fail(who, "length stop outside 1..max_new_tokens");
+    if (limits && T + lim > c.max_seq) return fail(who, "prompt + length stop exceeds max_seq");
+    pm.slot[i] = slots[i];
+    in.kbeg[i] = left_pad[i];
+    in.limit[i] = lim;
   }
-  HIPCHK(hipMemcpyAsync(e->d_unf + row0, hp, n * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(e->d_kbeg + row0, hp + 16, n * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(e->d_curlen + row0, hp + 32, n * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(e->d_rowstep + row0, hp + 48, n * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(e->d_limit + row0, hp + 64, n * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(e->d_tokens + (size_t)row0 * e->c.max_new_tokens), e->c.pad_token_id,
-                           (size_t)n * e->c.max_new_tokens, s));
+  in.map = pm; in.k = k; in.T = T; in.pad_id = c.pad_token_id; in.out_ld = c.max_new_tokens;
+  in.unfinished = e->d_unf; in.kbeg_state = e->d_kbeg; in.cur_len = e->d_curlen; in.row_step = e->d_rowstep; in.limit_state = e->d_limit;
+  in.tokens = e->d_tokens; in.pf_kbeg = e->d_pfkbeg;
+  HIPCHK(launch_slot_init(in, s));
+  const int d = c.d_model, M = k * T;
+  HIPCHK(hipMemcpyAsync(e->w_h, embeds, (size_t)M * d * 2, hipMemcpyDeviceToDevice, s));
+  ORCCHK(llama_prefill_layers(e, e->w_h, e->w_xn, e->w_qkv, e->w_att, e->w_mlp, k, T, position_ids, s, pm));
+  // last position of every (left-padded) row: row b*T + T-1  -> stride T*d
+  ORCCHK(head_and_sample(e, e->w_h + (size_t)(T - 1) * d, T * d, k, logits_out, false, s, pm));
   return 0;
 }
 
 extern "C" int orc_prefill(orc_engine* e, const void* embeds, const int32_t* position_ids, const int32_t* left_pad,
                            int B, int T, float* logits_out, void* stream) {
   if (!e || !e->finalized) return fail("orc_prefill", "engine not finalized");
-  const orc_config& c = e->c;
   hipStream_t s = S(stream);
-  if (B < 1 || B > c.max_batch) return fail("orc_prefill", "batch outside 1..max_batch");
-  if (T < 1 || T >= c.max_seq) return fail("orc_prefill", "prompt length exceeds max_seq");
-  if (B * T > e->ws_rows) return fail("orc_prefill", "batch*T exceeds workspace");
-  for (int b = 0; b < B; ++b)
-    if (left_pad[b] < 0 || left_pad[b] >= T) return fail("orc_prefill", "left_pad outside 0..T-1");
+  if (B < 1 || B > e->c.max_batch) return fail("orc_prefill", "batch outside 1..max_batch");
+  int slots[16];
+  for (int i = 0; i < 16; ++i) {
+    slots[i] = i;
+    e->row_map.slot[i] = i < B ? i : -1;   // decode row b <-> slot b
+  }
   e->stream_mode = false;
   e->cur_batch = B;
   e->cur_T = T;
   e->steps_issued = 0;
-  HIPCHK(hipMemsetAsync(e->dev_ints, 0, 16 * 4, s));                      // step = 0, n_unfinished set by the sampler
-  HIPCHK(hipMemsetAsync(e->d_unf, 0, 16 * 4, s));                         // rows >= B: finished
-  ORCCHK(reset_rows(e, 0, B, left_pad, T, c.max_new_tokens, s));
-  const int d = c.d_model, M = B * T;
-  HIPCHK(hipMemcpyAsync(e->w_h, embeds, (size_t)M * d * 2, hipMemcpyDeviceToDevice, s));
-  ORCCHK(llama_prefill_layers(e, e->w_h, e->w_xn, e->w_qkv, e->w_att, e->w_mlp, B, T, position_ids, s));
-  // last position of every (left-padded) row: row b*T + T-1  -> stride T*d
-  ORCCHK(head_and_sample(e, e->w_h + (size_t)(T - 1) * d, T * d, B, logits_out, false, s));
-  return 0;
+  HIPCHK(hipMemsetAsync(e->dev_ints, 0, 16 * 4, s));   // step = 0; n_unfinished is set by the sampler
+  return prefill_into_slots(e, slots, B, embeds, position_ids, left_pad, nullptr, T, logits_out, s, "orc_prefill");
 }
 
 // decode step k (1-based since the prefill) writes K/V slot T + k - 1 of every row: refuse the step that would leave the
@@ -801,11 +810,11 @@ static int decode_one(orc_engine* e, const int32_t* forced, float* logits_out, h
   const orc_config& c = e->c;
   const int B = e->cur_batch;
   ++e->steps_issued;
-  HIPCHK(launch_embed_tokens(forced ? forced : e->d_next, e->embed, e->d_h, B, c.d_model, c.vocab, e->d_ssq, c.d_model / 16, s, e->d_hxf));
+  HIPCHK(launch_embed_tokens(forced, e->d_next, e->row_map, e->embed, e->d_h, B, c.d_model, c.vocab, e->d_ssq, c.d_model / 16, s, e->d_hxf));
   // free-running: finished rows freeze (their tokens are pad, their cache is not read or grown); teacher forcing: every
   // row advances with the forced token whatever the sampler thinks
   ORCCHK(llama_decode_layers(e, B, s, forced == nullptr));
-  ORCCHK(head_and_sample(e, e->d_h, c.d_model, B, logits_out, true, s, 0, forced == nullptr));
+  ORCCHK(head_and_sample(e, e->d_h, c.d_model, B, logits_out, true, s, e->row_map, forced == nullptr));
   return 0;
 }
 
@@ -826,6 +835,7 @@ extern "C" int orc_decode_steps(orc_engine* e, int n_steps, void* stream) {
 extern "C" int orc_read_state(orc_engine* e, int32_t* tokens_host, int32_t* steps_host, int32_t* n_unf_host,
                               int32_t* last_argmax_host, void* stream) {
   if (!e || !e->finalized) return fail("orc_read_state", "engine not finalized");
+  if (e->stream_mode) return fail("orc_read_state", "use orc_read_slots between orc_stream_begin and the next orc_prefill");
   hipStream_t s = S(stream);
   int hdr[16];
   HIPCHK(hipMemcpyAsync(hdr, e->dev_ints, 16 * 4, hipMemcpyDeviceToHost, s));
@@ -842,48 +852,48 @@ extern "C" int orc_read_state(orc_engine* e, int32_t* tokens_host, int32_t* step
 extern "C" int orc_set_row_limits(orc_engine* e, const int32_t* limits_host, int n, void* stream) {
   if (!e || !e->finalized || e->cur_batch == 0) return fail("orc_set_row_limits", "no prefill has run");
   if (!limits_host || n != e->cur_batch) return fail("orc_set_row_limits", "one limit per row of the running batch");
-  hipStream_t s = S(stream);
-  HIPCHK(hipStreamSynchronize(s));   // pinned staging reuse
+  ScatterArgs sa = {};
+  sa.map = e->row_map; sa.n = n; sa.dst = e->d_limit;
   for (int i = 0; i < n; ++i) {
     if (limits_host[i] < 1 || limits_host[i] > e->c.max_new_tokens) return fail("orc_set_row_limits", "limit outside 1..max_new_tokens");
-    e->h_pinned[i] = limits_host[i];
+    sa.val[i] = limits_host[i];
   }
-  HIPCHK(hipMemcpyAsync(e->d_limit, e->h_pinned, n * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(launch_scatter_ints(sa, S(stream)));
   return 0;
 }
 
 // ---------------------------------------------------------------------------- continuous batching
-extern "C" int orc_stream_begin(orc_engine* e, int n_slots, void* stream) {
+extern "C" int orc_stream_begin(orc_engine* e, int n_rows, void* stream) {
   if (!e || !e->finalized) return fail("orc_stream_begin", "engine not finalized");
-  if (n_slots < 1 || n_slots > e->c.max_batch) return fail("orc_stream_begin", "n_slots outside 1..max_batch");
+  if (n_rows < 1 || n_rows > e->c.max_batch) return fail("orc_stream_begin", "n_rows outside 1..max_batch");
   hipStream_t s = S(stream);
   e->stream_mode = true;
-  e->cur_batch = n_slots;
+  e->cur_batch = n_rows;
   e->cur_T = 0;
   e->steps_issued = 0;
-  for (int i = 0; i < 16; ++i) e->slot_T[i] = 0;
-  // every slot empty = finished, with one harmless cached key so that a decode step over it stays in bounds
+  for (int i = 0; i < 16; ++i) e->row_map.slot[i] = -1;   // no decode row is attached to a slot yet
   HIPCHK(hipMemsetAsync(e->dev_ints, 0, DI_TOKENS * 4, s));
-  HIPCHK(hipMemsetD32Async((hipDeviceptr_t)e->d_curlen, 1, 16, s));
-  HIPCHK(hipMemsetD32Async((hipDeviceptr_t)e->d_limit, 1, 16, s));
   return 0;
 }
 
-extern "C" int orc_prefill_slot(orc_engine* e, int slot, const void* embeds, int T, int max_new, float* logits_out, void* stream) {
-  if (!e || !e->finalized) return fail("orc_prefill_slot", "engine not finalized");
-  if (!e->stream_mode) return fail("orc_prefill_slot", "call orc_stream_begin first");
-  const orc_config& c = e->c;
-  hipStream_t s = S(stream);
-  if (slot < 0 || slot >= e->cur_batch) return fail("orc_prefill_slot", "slot outside the running batch");
-  if (max_new < 1 || max_new > c.max_new_tokens) return fail("orc_prefill_slot", "length stop outside 1..max_new_tokens");
-  if (T < 1 || T + max_new > c.max_seq) return fail("orc_prefill_slot", "prompt + length stop exceeds max_seq");
-  if (T > e->ws_rows) return fail("orc_prefill_slot", "T exceeds workspace");
-  ORCCHK(reset_rows(e, slot, 1, nullptr, T, max_new, s));
-  e->slot_T[slot] = T;
-  const int d = c.d_model;
-  HIPCHK(hipMemcpyAsync(e->w_h, embeds, (size_t)T * d * 2, hipMemcpyDeviceToDevice, s));
-  ORCCHK(llama_prefill_layers(e, e->w_h, e->w_xn, e->w_qkv, e->w_att, e->w_mlp, 1, T, e->d_iota, s, slot));
-  ORCCHK(head_and_sample(e, e->w_h + (size_t)(T - 1) * d, T * d, 1, logits_out, false, s, slot));
+extern "C" int orc_prefill_slots(orc_engine* e, const int32_t* slots_host, int n, const void* embeds, const int32_t* position_ids,
+                                 const int32_t* left_pad_host, const int32_t* limits_host, int T, float* logits_out, void* stream) {
+  if (!e || !e->finalized) return fail("orc_prefill_slots", "engine not finalized");
+  if (!e->stream_mode) return fail("orc_prefill_slots", "call orc_stream_begin first");
+  if (!slots_host || !embeds || !position_ids || !left_pad_host || !limits_host) return fail("orc_prefill_slots", "null argument");
+  for (int i = 0; i < n && i < 16; ++i)
+    for (int r = 0; r < e->cur_batch; ++r)
+      if (e->row_map.slot[r] == slots_host[i]) return fail("orc_prefill_slots", "slot is attached to a decode row");
+  return prefill_into_slots(e, slots_host, n, embeds, position_ids, left_pad_host, limits_host, T, logits_out, S(stream), "orc_prefill_slots");
+}
+
+extern "C" int orc_stream_attach(orc_engine* e, int row, int slot) {
+  if (!e || !e->finalized || !e->stream_mode) return fail("orc_stream_attach", "call orc_stream_begin first");
+  if (row < 0 || row >= e->cur_batch) return fail("orc_stream_attach", "row outside the decode width");
+  if (slot < -1 || slot >= e->c.max_batch) return fail("orc_stream_attach", "slot outside -1..max_batch-1");
+  for (int r = 0; r < e->cur_batch; ++r)
+    if (slot >= 0 && r != row && e->row_map.slot[r] == slot) return fail("orc_stream_attach", "slot is attached to another row");
+  e->row_map.slot[row] = slot;
   return 0;
 }
 
@@ -891,8 +901,7 @@ extern "C" int orc_read_slots(orc_engine* e, int32_t* tokens_host, int32_t* row_
                               void* stream) {
   if (!e || !e->finalized) return fail("orc_read_slots", "engine not finalized");
   hipStream_t s = S(stream);
-  const int B = e->cur_batch;
-  if (B < 1) return fail("orc_read_slots", "no running batch");
+  const int B = e->c.max_batch;
   if (tokens_host) HIPCHK(hipMemcpyAsync(tokens_host, e->d_tokens, (size_t)B * e->c.max_new_tokens * 4, hipMemcpyDeviceToHost, s));
   if (row_steps_host) HIPCHK(hipMemcpyAsync(row_steps_host, e->d_rowstep, (size_t)B * 4, hipMemcpyDeviceToHost, s));
   if (unfinished_host) HIPCHK(hipMemcpyAsync(unfinished_host, e->d_unf, (size_t)B * 4, hipMemcpyDeviceToHost, s));
@@ -1015,6 +1024,7 @@ extern "C" int orc_test_decode_attention(const void* q, const void* kcache, cons
   DecodeAttnArgs a;
   a.o_xf = 0;
   a.unfinished = nullptr;
+  a.map = identity_map();
   a.Q = (const bf16_t*)q; a.q_bs = (long)H * 128; a.Kc = (const bf16_t*)kcache; a.Vc = (const bf16_t*)vcache;
   a.c_hs = (long)Tmax * 128; a.c_bs = a.c_hs * H; a.O = (bf16_t*)out; a.o_bs = (long)H * 128;
   a.part = part; a.kbeg = ints + 16; a.cur_len = ints; a.B = B; a.H = H; a.scale = 0.08838834764831845f;

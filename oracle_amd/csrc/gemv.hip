@@ -100,8 +100,10 @@ __device__ __forceinline__ void epilogue_pair(const GemvArgs& a, const float (*r
     // rows were packed so that tile 0 holds head dims [d0, d0+16) and tile 1 their rotary partners [d0+64, ...)
     const int hs = pair >> 2, d = (pair & 3) * 16 + 4 * g;
     const int sec = hs / a.H, h = hs % a.H;
-    const int len = a.cur_len[b];
-    const int pos_raw = len - 1 - a.kbeg[b];
+    const int sl = a.map.slot[b];
+    if (sl < 0) return;                                              // inactive decode row
+    const int len = a.cur_len[sl];
+    const int pos_raw = len - 1 - a.kbeg[sl];
     const int pos = pos_raw < 0 ? 0 : (pos_raw >= a.maxpos ? a.maxpos - 1 : pos_raw);
     const int slot = len - 1;
     float lo[4], hi[4];
@@ -125,7 +127,7 @@ __device__ __forceinline__ void epilogue_pair(const GemvArgs& a, const float (*r
     if (sec == 0)
       dst = (bf16_t*)a.C + (size_t)b * a.ldc + h * 128 + d;
     else
-      dst = (sec == 1 ? a.Kc : a.Vc) + (size_t)b * a.c_bs + (size_t)h * a.c_hs + (size_t)slot * 128 + d;
+      dst = (sec == 1 ? a.Kc : a.Vc) + (size_t)sl * a.c_bs + (size_t)h * a.c_hs + (size_t)slot * 128 + d;
     u32x2 s0 = {pack2(lo[0], lo[1]), pack2(lo[2], lo[3])};
     u32x2 s1 = {pack2(hi[0], hi[1]), pack2(hi[2], hi[3])};
     *(u32x2*)dst = s0;
@@ -495,6 +497,7 @@ hipError_t launch_gemv_pers(const GemvArgs& a, int epi, int waves, int u, int gr
 
 hipError_t launch_gemv(const GemmArgs& g, int epi, hipStream_t s) {
   GemvArgs a = {};
+  a.map = identity_map();
   a.X = g.X; a.ldx = g.ldx; a.Wp = g.Wp; a.bias = g.bias; a.R = g.R; a.ldr = g.ldr; a.C = g.C; a.ldc = g.ldc;
   a.M = g.M; a.N = g.N; a.K = g.K; a.Nvalid = g.Nvalid;
   return launch_gemv_ex(a, epi, 0, s);

@@ -8,6 +8,13 @@
 // records "what: detail" for orc_last_error() and returns -1 (engine.hip)
 int orc_fail(const char* what, const char* detail);
 
+// Row -> slot map, passed by value inside the kernel arguments: row b of a launch (a decode row, or a row of a prefill
+// batch) uses the per-slot greedy state and the KV-cache rows of slot[b]; -1 = inactive row (nothing read or written).
+// The host changes the map between launches without touching device memory (continuous batching: a finished frame's
+// decode row is pointed at a slot that was prefilled ahead of time).
+struct RowMap { int slot[16] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}; };   // default: row b <-> slot b
+inline RowMap identity_map() { return RowMap(); }
+
 enum { EPI_NONE = 0, EPI_QUICKGELU = 1, EPI_GELU = 2, EPI_RESIDUAL = 3, EPI_SWIGLU = 4, EPI_F32 = 5, EPI_ROPE_KV = 6 };
 
 struct GemmArgs {
@@ -34,7 +41,8 @@ struct GemvArgs {
   // EPI_RESIDUAL: when non-null, ssq_out[b * (N/16) + ntile] = sum of squares of the stored tile values of row b
   float* ssq_out;
   // EPI_ROPE_KV: W rows packed per head-section as (tile j, tile j+4) pairs; C = q output [M][H*128]
-  int H; const int* kbeg; const int* cur_len;   // cur_len[b]: cached keys of row b incl. the token of this step
+  int H; const int* kbeg; const int* cur_len;   // per SLOT: first valid key; cached keys incl. the token of this step
+  RowMap map;                                   // decode row -> slot (state and cache rows)
   const bf16_t* cos_tab; const bf16_t* sin_tab; int maxpos;
   bf16_t* Kc; bf16_t* Vc; long c_bs, c_hs;
   // decode-path activation buffers in the fragment-ordered layout (common.h xf_off): x_xf = X is, c_xf = C is written so
@@ -78,6 +86,8 @@ struct AttnArgs {
   int causal;        // key j visible to query i iff j <= i + q_off
   int q_off;
   float scale;
+  int kv_map_on = 0; // 1: K / V batch index of row b is kv_map.slot[b] (prefill into arbitrary KV-cache slots)
+  RowMap kv_map;
 };
 hipError_t launch_attention(const AttnArgs& a, int head_dim, hipStream_t s);
 
@@ -89,8 +99,9 @@ struct DecodeAttnArgs {
   bf16_t* O; long o_bs;                      // [B][H*128]
   float* part;                               // workspace [B][H][NSPLIT][2+128]
   const int* kbeg;                           // [B] left-pad offset
-  const int* cur_len;                        // [B] number of cached keys of each row incl. the new one
-  const int* unfinished;                     // [B] or null: rows whose flag is 0 are skipped (output zeros; their tokens are pad)
+  const int* cur_len;                        // per slot: number of cached keys incl. the new one
+  const int* unfinished = nullptr;           // per slot, or null: rows whose flag is 0 are skipped (output zeros; their tokens are pad)
+  RowMap map;                                // row -> slot (kbeg / cur_len / unfinished / cache rows); Q, O and part are per row
   int B, H;
   float scale;
   int o_xf;                                  // write O in the fragment-ordered layout (common.h xf_off), k = h * 128 + d
@@ -106,8 +117,9 @@ struct RopeArgs {
   const int* cur_len;         // decode mode: [B]; cache slot = cur_len[b] - 1
   const bf16_t* cos_tab; const bf16_t* sin_tab;   // [maxpos][64]
   int maxpos;
-  bf16_t* Kc; bf16_t* Vc; long c_bs, c_hs;        // cache [B][H][Tmax][128]
-  int t0;                     // prefill: cache slot of token t is t0 + t
+  bf16_t* Kc; bf16_t* Vc; long c_bs, c_hs;        // cache [slot][H][Tmax][128]
+  int t0;                     // prefill: cache position of token t is t0 + t
+  RowMap map;                 // batch row -> cache slot
 };
 hipError_t launch_rope_kv(const RopeArgs& a, hipStream_t s);
 
@@ -124,10 +136,11 @@ hipError_t launch_copy_rows(const bf16_t* src, long src_bs, bf16_t* dst, long ds
 // splice: out[r][:] = kind==0 ? 0 : table_kind[idx][:]   (code = kind<<28 | idx)
 hipError_t launch_gather_rows(const int* codes, const bf16_t* tok, const bf16_t* img, const bf16_t* desc, bf16_t* out,
                               int rows, int d, hipStream_t s);
-// out[r] = tok[ids[r]]; when ssq_part != null also part[r][0] = sum(out[r]^2), part[r][1..n_part) = 0; when out_xf != null the
-// rows are also written in the fragment-ordered layout (rows <= 16)
-hipError_t launch_embed_tokens(const int* ids, const bf16_t* tok, bf16_t* out, int rows, int d, int vocab,
-                               float* ssq_part, int n_part, hipStream_t s, bf16_t* out_xf = nullptr);
+// out[r] = tok[id_r], id_r = ids_by_row[r] when given (teacher forcing), else ids_by_slot[map.slot[r]] (inactive row: token 0);
+// when ssq_part != null also part[r][0] = sum(out[r]^2), part[r][1..n_part) = 0; when out_xf != null the rows are also
+// written in the fragment-ordered layout (rows <= 16)
+hipError_t launch_embed_tokens(const int* ids_by_row, const int* ids_by_slot, const RowMap& map, const bf16_t* tok, bf16_t* out,
+                               int rows, int d, int vocab, float* ssq_part, int n_part, hipStream_t s, bf16_t* out_xf = nullptr);
 hipError_t launch_view_reduce(const bf16_t* x, bf16_t* out, int B, int V, int n, int mode, hipStream_t s);
 hipError_t launch_pool2x2(const bf16_t* x, bf16_t* out, int n_img, int grid, int d, hipStream_t s);
 
@@ -139,19 +152,32 @@ hipError_t launch_preprocess(const uint8_t* img, int n, int H, int W, int out, c
 // started at different times -- continuous batching, orc_prefill_slot)
 struct SampleArgs {
   const float* logits; int vocab;
-  int B;               // rows sampled by this launch: logits row i belongs to state row row0 + i
-  int row0;
-  int n_rows;          // rows of the running batch (for the n_unfinished count)
-  int* unfinished;     // [n_rows]
-  int* next_ids;       // [n_rows] token fed to the next step
-  int* raw_argmax;     // [n_rows] argmax before the finished-row substitution (may be null)
-  int* out_tokens; int out_ld;   // [n_rows][max_new] generated tokens (pre-filled with pad at prefill)
-  int* row_step;       // [n_rows] tokens emitted so far by the frame in this row
-  int* cur_len;        // [n_rows] cached keys for the NEXT step incl. its token
-  const int* limit;    // [n_rows] length stop: the row is finished after emitting limit[b] tokens
+  int B;               // rows sampled by this launch: logits row i belongs to slot map.slot[i] (-1: skipped)
+  RowMap map;
+  RowMap count; int n_count;   // slots whose unfinished flags make up n_unfinished (the rows being decoded)
+  // per-slot state:
+  int* unfinished;
+  int* next_ids;       // token fed to the next step
+  int* raw_argmax;     // argmax before the finished-row substitution (may be null)
+  int* out_tokens; int out_ld;   // [slot][max_new] generated tokens (pre-filled with pad at prefill)
+  int* row_step;       // tokens emitted so far by the frame in this slot
+  int* cur_len;        // cached keys for the NEXT step incl. its token
+  const int* limit;    // length stop: the frame is finished after emitting limit[slot] tokens
   int* step;           // device scalar: sampling launches since the last batch prefill
   int* n_unfinished;   // device scalar: rows still unfinished after this step
   int pad_id, eos_id;
   int freeze_finished; // 1: a finished row stops advancing (keeps its cache slot and step); 0: teacher forcing, all rows advance
 };
 hipError_t launch_argmax_sample(const SampleArgs& a, hipStream_t s);
+
+// ---- per-slot greedy state (re)initialisation for a prefill: one block per prefilled row, everything by value
+struct SlotInitArgs {
+  RowMap map; int k;                 // prefill row i -> slot
+  int kbeg[16]; int limit[16];       // per prefill row: left pad, length stop
+  int T; int pad_id; int out_ld;
+  int *unfinished, *kbeg_state, *cur_len, *row_step, *limit_state, *tokens;   // per-slot state arrays
+  int* pf_kbeg;                      // [16] per prefill ROW copy of kbeg (read by the prefill attention)
+};
+hipError_t launch_slot_init(const SlotInitArgs& a, hipStream_t s);
+struct ScatterArgs { RowMap map; int n; int val[16]; int* dst; };   // dst[map.slot[i]] = val[i]
+hipError_t launch_scatter_ints(const ScatterArgs& a, hipStream_t s);

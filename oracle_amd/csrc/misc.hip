@@ -24,13 +24,15 @@ namespace {
 __global__ __launch_bounds__(256) void rope_kv_kernel(RopeArgs a) {
   const int row = blockIdx.x;
   const int b = row / a.T, t = row % a.T;
+  const int sl = a.map.slot[b];                 // KV-cache slot of this batch row
+  if (sl < 0) return;
   int pos, slot;
   if (a.pos) {
     pos = a.pos[row];
     slot = a.t0 + t;
   } else {
-    const int len = a.cur_len[b];
-    pos = len - 1 - a.kbeg[b];
+    const int len = a.cur_len[sl];
+    pos = len - 1 - a.kbeg[sl];
     slot = len - 1;
   }
   pos = pos < 0 ? 0 : (pos >= a.maxpos ? a.maxpos - 1 : pos);
@@ -42,8 +44,8 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(RopeArgs a) {
     const int head = u >> 3, c = u & 7;
     const u32x4 cs = *(const u32x4*)(a.cos_tab + (size_t)pos * 64 + c * 8);
     const u32x4 sn = *(const u32x4*)(a.sin_tab + (size_t)pos * 64 + c * 8);
-    bf16_t* kdst = a.Kc + (size_t)b * a.c_bs + (size_t)head * a.c_hs + (size_t)slot * 128;
-    bf16_t* vdst = a.Vc + (size_t)b * a.c_bs + (size_t)head * a.c_hs + (size_t)slot * 128;
+    bf16_t* kdst = a.Kc + (size_t)sl * a.c_bs + (size_t)head * a.c_hs + (size_t)slot * 128;
+    bf16_t* vdst = a.Vc + (size_t)sl * a.c_bs + (size_t)head * a.c_hs + (size_t)slot * 128;
 #pragma unroll
     for (int which = 0; which < 2; ++which) {
       bf16_t* src = (which == 0 ? qr : kr) + head * 128 + c * 8;
@@ -160,12 +162,14 @@ __global__ __launch_bounds__(128) void gather_rows_kernel(const int* __restrict_
   }
 }
 
-__global__ __launch_bounds__(128) void embed_tokens_kernel(const int* __restrict__ ids, const bf16_t* __restrict__ tok,
+__global__ __launch_bounds__(128) void embed_tokens_kernel(const int* __restrict__ ids_by_row, const int* __restrict__ ids_by_slot,
+                                                           RowMap map, const bf16_t* __restrict__ tok,
                                                            bf16_t* __restrict__ out, int d, int vocab,
                                                            float* __restrict__ ssq_part, int n_part, bf16_t* __restrict__ out_xf) {
   __shared__ float sh[2];
   const int row = blockIdx.x;
-  int id = ids[row];
+  const int sl = map.slot[row];
+  int id = ids_by_row ? ids_by_row[row] : (sl < 0 ? 0 : ids_by_slot[sl]);
   id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
   float ss = 0.f;
   for (int c = threadIdx.x; c < (d >> 3); c += 128) {
@@ -277,7 +281,8 @@ __global__ __launch_bounds__(128) void resize_v_kernel(const uint8_t* __restrict
 __global__ __launch_bounds__(1024) void argmax_sample_kernel(SampleArgs a) {   // 16 waves per row: 8 loads per thread at 32000
   __shared__ float sv[16];
   __shared__ int si[16];
-  const int b = a.row0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int b = a.map.slot[blockIdx.x], tid = threadIdx.x, lane = tid & 63, w = tid >> 6;   // b = the slot whose state this row owns
+  if (b < 0) return;
   const float* lg = a.logits + (size_t)blockIdx.x * a.vocab;
   float best = -INFINITY;
   int bi = 0x7fffffff;
@@ -318,10 +323,33 @@ __global__ __launch_bounds__(1024) void argmax_sample_kernel(SampleArgs a) {   /
 __global__ void step_advance_kernel(SampleArgs a) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     int n = 0;
-    for (int b = 0; b < a.n_rows; ++b) n += a.unfinished[b] ? 1 : 0;
+    for (int i = 0; i < a.n_count; ++i) {
+      const int sl = a.count.slot[i];
+      n += (sl >= 0 && a.unfinished[sl]) ? 1 : 0;
+    }
     *a.n_unfinished = n;
     *a.step += 1;
   }
+}
+
+// unfinished = 1, kbeg, cur_len = T (keys cached after the prefill; the sampler advances it to T + 1 for the first decode
+// step), step 0, the length stop; the slot's token row is filled with pad
+__global__ __launch_bounds__(256) void slot_init_kernel(SlotInitArgs a) {
+  const int i = blockIdx.x, sl = a.map.slot[i];
+  if (sl < 0) return;
+  if (threadIdx.x == 0) {
+    a.unfinished[sl] = 1;
+    a.kbeg_state[sl] = a.kbeg[i];
+    a.cur_len[sl] = a.T;
+    a.row_step[sl] = 0;
+    a.limit_state[sl] = a.limit[i];
+    a.pf_kbeg[i] = a.kbeg[i];
+  }
+  for (int t = threadIdx.x; t < a.out_ld; t += 256) a.tokens[(size_t)sl * a.out_ld + t] = a.pad_id;
+}
+__global__ void scatter_ints_kernel(ScatterArgs a) {
+  const int i = threadIdx.x;
+  if (i < a.n && a.map.slot[i] >= 0) a.dst[a.map.slot[i]] = a.val[i];
 }
 
 inline int grid_for(size_t total) {
@@ -367,11 +395,12 @@ hipError_t launch_gather_rows(const int* codes, const bf16_t* tok, const bf16_t*
   hipLaunchKernelGGL(gather_rows_kernel, dim3(rows), dim3(128), 0, s, codes, tok, img, desc, out, d);
   return hipGetLastError();
 }
-hipError_t launch_embed_tokens(const int* ids, const bf16_t* tok, bf16_t* out, int rows, int d, int vocab, float* ssq_part,
-                               int n_part, hipStream_t s, bf16_t* out_xf) {
+hipError_t launch_embed_tokens(const int* ids_by_row, const int* ids_by_slot, const RowMap& map, const bf16_t* tok, bf16_t* out,
+                               int rows, int d, int vocab, float* ssq_part, int n_part, hipStream_t s, bf16_t* out_xf) {
   if (rows <= 0) return hipSuccess;
-  if (out_xf && rows > 16) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(embed_tokens_kernel, dim3(rows), dim3(128), 0, s, ids, tok, out, d, vocab, ssq_part, n_part, out_xf);
+  if (rows > 16) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(embed_tokens_kernel, dim3(rows), dim3(128), 0, s, ids_by_row, ids_by_slot, map, tok, out, d, vocab, ssq_part,
+                     n_part, out_xf);
   return hipGetLastError();
 }
 hipError_t launch_view_reduce(const bf16_t* x, bf16_t* out, int B, int V, int n, int mode, hipStream_t s) {
@@ -391,8 +420,18 @@ hipError_t launch_preprocess(const uint8_t* img, int n, int H, int W, int out, c
   hipLaunchKernelGGL(resize_v_kernel, dim3(out, n), dim3(128), 0, s, tmp, S, out, bounds, coef, ksize, lut, dst);
   return hipGetLastError();
 }
+hipError_t launch_slot_init(const SlotInitArgs& a, hipStream_t s) {
+  if (a.k < 1 || a.k > 16) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(slot_init_kernel, dim3(a.k), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_scatter_ints(const ScatterArgs& a, hipStream_t s) {
+  if (a.n < 1 || a.n > 16) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(scatter_ints_kernel, dim3(1), dim3(64), 0, s, a);
+  return hipGetLastError();
+}
 hipError_t launch_argmax_sample(const SampleArgs& a, hipStream_t s) {
-  if ((a.vocab & 3) || a.B <= 0) return hipErrorInvalidValue;
+  if ((a.vocab & 3) || a.B <= 0 || a.B > 16 || a.n_count > 16) return hipErrorInvalidValue;
   hipLaunchKernelGGL(argmax_sample_kernel, dim3(a.B), dim3(1024), 0, s, a);
   hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, s, a);
   return hipGetLastError();

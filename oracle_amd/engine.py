@@ -179,22 +179,29 @@ class Engine:
         return t, steps.value, nunf.value, torch.tensor(list(am), dtype=torch.long)
 
     # ------------------------------------------------------------------ continuous batching
-    def stream_begin(self, n_slots):
-        _lib.check(self.lib.orc_stream_begin(self._h, int(n_slots), _stream()), 'orc_stream_begin')
-        self.batch = int(n_slots)
+    def stream_begin(self, n_rows):
+        """n_rows decode rows, none attached to a slot yet (the engine has max_batch KV-cache slots)."""
+        _lib.check(self.lib.orc_stream_begin(self._h, int(n_rows), _stream()), 'orc_stream_begin')
+        self.batch = int(n_rows)
 
-    def prefill_slot(self, slot, embeds, max_new, want_logits=False):
-        """embeds (T, D) bf16: one unpadded spliced prompt into row `slot` of the running batch; max_new = its length stop."""
+    def prefill_slots(self, slots, embeds, position_ids, left_pad, limits, want_logits=False):
+        """embeds (n, T, D) bf16 left-padded, position_ids (n, T), into the unattached KV slots `slots`; limits = length stops."""
         _chk_bf16(embeds, 'embeds')
-        t = embeds.shape[0]
-        logits = torch.empty(1, self.dims.vocab, dtype=torch.float32, device=embeds.device) if want_logits else None
-        _lib.check(self.lib.orc_prefill_slot(self._h, int(slot), _ptr(embeds), t, int(max_new), _ptr(logits), _stream()), 'orc_prefill_slot')
+        n, t, _ = embeds.shape
+        pos = position_ids.to(device=embeds.device, dtype=torch.int32).contiguous()
+        arr = lambda xs: (C.c_int32 * n)(*[int(x) for x in xs])
+        logits = torch.empty(n, self.dims.vocab, dtype=torch.float32, device=embeds.device) if want_logits else None
+        _lib.check(self.lib.orc_prefill_slots(self._h, arr(slots), n, _ptr(embeds), _ptr(pos), arr(left_pad), arr(limits), t,
+                                              _ptr(logits), _stream()), 'orc_prefill_slots')
         return logits
 
+    def stream_attach(self, row, slot):
+        _lib.check(self.lib.orc_stream_attach(self._h, int(row), int(slot)), 'orc_stream_attach')
+
     def read_slots(self):
-        """-> (tokens (n_slots, max_new_tokens) int64 CPU tensor, tokens emitted per row (list), unfinished flags (list))"""
+        """-> (tokens (max_batch, max_new_tokens) int64 CPU tensor, tokens emitted per slot (list), unfinished flags (list))"""
         import numpy as np
-        b = self.batch
+        b = self.max_batch
         toks = np.empty((b, self.max_new_tokens), dtype=np.int32)
         steps = (C.c_int32 * b)()
         unf = (C.c_int32 * b)()

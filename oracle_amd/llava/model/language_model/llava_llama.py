@@ -209,32 +209,39 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
 
     # ------------------------------------------------------------------ continuous batching
     @torch.no_grad()
-    def generate_stream(self, batches, max_new_tokens=20, n_slots=None, chunk=8, do_sample=False, use_cache=True,
+    def generate_stream(self, batches, max_new_tokens=20, n_rows=None, chunk=8, do_sample=False, use_cache=True,
                         stopping_criteria=None):
-        """generate() over a stream of batches with slot refill. The reference decodes batch after
-        batch (scene_graph_prediction_model_oracle.py:251-260) and every batch runs as long as its longest answer; frames
-        are independent, so here a row of the running batch whose frame has finished (EOS / length stop) is refilled with
-        the next frame (single-row LLaMA prefill into that row's KV slot, orc_prefill_slot) while the others keep decoding.
-        Vision, pooling, projection and the splice still run per incoming batch, as in generate().
+        """generate() over a stream of batches with continuous batching. The reference decodes batch
+        after batch (scene_graph_prediction_model_oracle.py:251-260) and every batch runs as long as its longest answer;
+        frames are independent, so here a decode row whose frame has finished (EOS / length stop) continues with the next
+        frame. The engine has max_batch KV-cache slots and decodes n_rows rows (default: half the slots, at least 1): the
+        next incoming batch is prefilled AHEAD, as one left-padded batch (same kernels and shapes as generate()), into the
+        free slots while the current frames decode, and a finished row is simply re-attached to a waiting slot. Vision,
+        pooling, projection and the splice run per incoming batch, exactly as in generate().
 
         batches: iterable of dicts {'input_ids': (B, L) LongTensor, 'images': ..., 'vis_descriptor_embs': ... or None,
-        'limits': optional per-row length stops (synthetic workloads), 'stopping_criteria': optional, per batch}. Yields, in input order, what generate() returns
-        for each batch: (B, L + n) = input_ids ++ new tokens, rows that finished early filled with pad, n = the
-        longest row of that batch. Greedy tokens of a row do not depend on its neighbours (the decode GEMVs are
-        bit-invariant to the batch), so the results equal generate() batch by batch."""
+        'limits': optional per-row length stops (synthetic workloads), 'stopping_criteria': optional, per batch}. Yields,
+        in input order, what generate() returns for each batch: (B, L + n) = input_ids ++ new tokens, rows that finished
+        early filled with pad, n = the longest row of that batch. A row's greedy tokens do not depend on its neighbours
+        (the decode GEMVs are bit-invariant to the batch), so the results equal generate() batch by batch."""
         if do_sample:
             raise NotImplementedError('only greedy decoding (do_sample=False) is implemented, as ORacle uses')
         eng = self.engine
         if max_new_tokens > eng.max_new_tokens:
             raise ValueError(f'max_new_tokens {max_new_tokens} exceeds the engine capacity {eng.max_new_tokens}')
-        n_slots = eng.max_batch if n_slots is None else n_slots
+        n_slots = eng.max_batch
+        n_rows = max(1, n_slots // 2) if n_rows is None else n_rows
+        if not 1 <= n_rows <= n_slots:
+            raise ValueError(f'n_rows {n_rows} outside 1..{n_slots} (the engine\'s KV-cache slots)')
         pad, eos = self.config.pad_token_id, self.config.eos_token_id
         it = iter(batches)
-        info = {}                       # batch index -> {'ids', 'rows': {row: tokens}, 'n'}
-        queue = []                      # prepared rows waiting for a slot: (batch index, row, embeds (T, D), length stop)
-        slots = [None] * n_slots        # (batch index, row, length stop) of the frame decoding in each slot
+        info = {}                       # batch index -> {'ids', 'rows': {row: tokens}, 'n', 'stopping'}
+        queue = []                      # prepared frames waiting for a slot: (batch index, row, embeds (T, D), length stop)
+        free = list(range(n_slots))     # KV-cache slots holding nothing
+        waiting = []                    # prefilled, not yet decoding: (slot, batch index, row)
+        rows = [None] * n_rows          # decoding: (slot, batch index, row) per decode row
         next_in, next_out, exhausted = 0, 0, False
-        eng.stream_begin(n_slots)
+        eng.stream_begin(n_rows)
 
         def prepare():
             nonlocal next_in, exhausted
@@ -260,15 +267,45 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
             t = embeds.shape[1]
             for b in range(ids.shape[0]):
                 lim = max_new_tokens if limits is None else min(int(limits[b]), max_new_tokens)
-                if counts[b] + lim > eng.max_seq:
-                    if counts[b] >= eng.max_seq:
-                        raise ValueError(f'prompt ({counts[b]}) exceeds the KV capacity {eng.max_seq}')
-                    warnings.warn(f'prompt ({counts[b]}) + max_new_tokens ({lim}) exceeds the KV capacity {eng.max_seq}: '
-                                  f'generating at most {eng.max_seq - counts[b]} tokens')
-                    lim = eng.max_seq - counts[b]
+                if t + lim > eng.max_seq:      # t: the row may be prefilled at its batch's padded length
+                    if t >= eng.max_seq:
+                        raise ValueError(f'prompt ({t}) exceeds the KV capacity {eng.max_seq}')
+                    warnings.warn(f'prompt ({t}) + max_new_tokens ({lim}) exceeds the KV capacity {eng.max_seq}: '
+                                  f'generating at most {eng.max_seq - t} tokens')
+                    lim = eng.max_seq - t
                 queue.append((next_in, b, embeds[b, t - counts[b]:], lim))
             info[next_in] = {'ids': ids, 'rows': {}, 'n': ids.shape[0], 'stopping': item.get('stopping_criteria', stopping_criteria)}
             next_in += 1
+
+        def prefill(k):
+            """the first k queued frames, as one left-padded batch, into k free slots"""
+            frames = [queue.pop(0) for _ in range(k)]
+            slots = [free.pop(0) for _ in range(k)]
+            lens = [f[2].shape[0] for f in frames]
+            t = max(lens)
+            emb = torch.zeros(k, t, frames[0][2].shape[1], dtype=torch.bfloat16, device=frames[0][2].device)
+            pos = torch.zeros(k, t, dtype=torch.int32)
+            for i, f in enumerate(frames):
+                emb[i, t - lens[i]:] = f[2]
+                pos[i, t - lens[i]:] = torch.arange(lens[i], dtype=torch.int32)
+            eng.prefill_slots(slots, emb, pos, [t - n for n in lens], [min(f[3], eng.max_seq - t) for f in frames])
+            waiting.extend((s_, f[0], f[1]) for s_, f in zip(slots, frames))
+
+        def schedule():
+            """attach waiting slots to idle rows; prefill ahead when a batch worth of slots is free, or at once when a row
+            would otherwise idle"""
+            while True:
+                for r in range(n_rows):
+                    if rows[r] is None and waiting:
+                        rows[r] = waiting.pop(0)
+                        eng.stream_attach(r, rows[r][0])
+                if not queue and not exhausted:
+                    prepare()
+                k = min(len(free), len(queue), n_rows)
+                starving = any(x is None for x in rows) and not waiting
+                if k == 0 or (not starving and k < min(n_rows, len(queue))):
+                    return
+                prefill(k)
 
         def finished_batches():
             nonlocal next_out
@@ -289,22 +326,19 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
                 yield out
 
         while True:
-            for s_ in range(n_slots):                                   # refill every free slot
-                if slots[s_] is None:
-                    if not queue and not exhausted:
-                        prepare()
-                    if queue:
-                        bi, row, emb, lim = queue.pop(0)
-                        eng.prefill_slot(s_, emb, lim)
-                        slots[s_] = (bi, row, lim)
-            if all(x is None for x in slots):
+            schedule()
+            if all(x is None for x in rows):
                 break
             eng.decode_steps(chunk)
+            if len(queue) < n_rows and not exhausted:      # host work of the next batch overlaps the decode chunk
+                prepare()
             toks, steps, unf = eng.read_slots()
-            for s_ in range(n_slots):
-                if slots[s_] is not None and not unf[s_]:
-                    bi, row, lim = slots[s_]
-                    info[bi]['rows'][row] = toks[s_, :steps[s_]].tolist()
-                    slots[s_] = None
+            for r in range(n_rows):
+                if rows[r] is not None and not unf[rows[r][0]]:
+                    slot, bi, row = rows[r]
+                    info[bi]['rows'][row] = toks[slot, :steps[slot]].tolist()
+                    eng.stream_attach(r, -1)
+                    free.append(slot)
+                    rows[r] = None
             yield from finished_batches()
         yield from finished_batches()

@@ -77,7 +77,19 @@ class DevicePreprocessor:
 
     def __call__(self, views):
         if isinstance(views, (list, tuple)):
-            views = torch.stack([torch.as_tensor(np.ascontiguousarray(v)) for v in views])
+            # stack straight into pinned host memory (torch caches pinned blocks and keeps one alive until the async copy
+            # that reads it has run), so the upload is one DMA that does not block the host
+            first = np.asarray(views[0])
+            if first.dtype != np.uint8 or first.ndim != 3 or first.shape[-1] != 3:
+                raise ValueError('views must be uint8 (H, W, 3)')
+            stage = torch.empty((len(views),) + first.shape, dtype=torch.uint8, pin_memory=self.device.type == 'cuda')
+            dst = stage.numpy()
+            for i, v in enumerate(views):
+                v = np.asarray(v)
+                if v.shape != first.shape:
+                    raise ValueError('views of one call must have one size')
+                dst[i] = v
+            views = stage
         if views.dtype != torch.uint8 or views.dim() != 4 or views.shape[-1] != 3:
             raise ValueError('views must be uint8 (n, H, W, 3)')
         x = views.to(self.device, non_blocking=True).contiguous()

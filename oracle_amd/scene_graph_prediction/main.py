@@ -44,6 +44,9 @@ def main(argv=None):
     ap.add_argument('--model_path', type=str, default=None, help='path to model checkpoint')
     ap.add_argument('--mode', type=str, default='evaluate', choices=['evaluate', 'infer'])
     ap.add_argument('--limit_frames', type=int, default=None, help='synthetic split size (default: 4D-OR split size)')
+    ap.add_argument('--image_size', type=str, default='336x336', help='synthetic camera image size WxH (4D-OR: 2048x1536)')
+    ap.add_argument('--image_format', type=str, default='png', choices=['png', 'jpg'], help='synthetic camera image files')
+    ap.add_argument('--decode_workers', type=int, default=None, help='image-decode threads (0: decode in the main thread, as the reference)')
     args = ap.parse_args(argv)
     seed_everything(42)
     config = config_loader(args.config)
@@ -59,10 +62,13 @@ def main(argv=None):
     split = 'val' if args.mode == 'evaluate' else 'test'
     print(f'Model path: {args.model_path}')
     train_dataset = SyntheticORDataset(config, 'train', n_frames=0, mv_desc=mv_desc)
-    eval_dataset = SyntheticORDataset(config, split, n_frames=args.limit_frames, for_eval=args.mode == 'infer', mv_desc=mv_desc)
+    w_, h_ = (int(x) for x in args.image_size.lower().split('x'))
+    eval_dataset = SyntheticORDataset(config, split, n_frames=args.limit_frames, for_eval=args.mode == 'infer', mv_desc=mv_desc,
+                                      image_size=(w_, h_), image_format=args.image_format)
     model = OracleWrapper(config, num_class=len(eval_dataset.classNames), num_rel=len(eval_dataset.relationNames),
                           weights_obj=train_dataset.w_cls_obj, weights_rel=train_dataset.w_cls_rel,
-                          relationNames=train_dataset.relationNames, model_path=args.model_path, mv_desc=mv_desc)
+                          relationNames=train_dataset.relationNames, model_path=args.model_path, mv_desc=mv_desc,
+                          **({} if args.decode_workers is None else {'decode_workers': args.decode_workers}))
     takes = [int(s.split('_')[0]) for s in eval_dataset.scans]
     mine = parallel.shard_indices(len(eval_dataset), rank, world, groups=takes if temporal else None)
     results = model.validate(batches(eval_dataset, batch_size, mine), return_raw_predictions=True, report=world == 1)

@@ -2,8 +2,10 @@
 
 Emits the per-frame dict the hot path consumes (reference or_dataset.py:82-93,98-163): `image_paths` (6 camera
 slots), `scan_id` "{take}_{pcd}_{split}", `take_idx`, `relations_tokenized` [(sub, rel, obj) vocabulary ids] and,
-with USE_VIS_DESC, `vis_descriptor_embs` (7 tensors). Images are seeded noise written once as PNG files; the split
-sizes follow 4D-OR (test: takes 2 and 6, 1378 frames; val: takes 4 and 8, 1332 frames)."""
+with USE_VIS_DESC, `vis_descriptor_embs` (7 tensors). Images are seeded noise written once as PNG files (default, 336 x 336)
+or, with image_format='jpg', image-like content (smooth colour fields + mild noise) as JPEG at any size -- 2048 x 1536 is
+what the 4D-OR cameras deliver, so the host-side decode cost of the drop-in CLI can be measured at the
+real size. The split sizes follow 4D-OR (test: takes 2 and 6, 1378 frames; val: takes 4 and 8, 1332 frames)."""
 import os
 import random
 
@@ -18,7 +20,7 @@ SPLIT_FRAMES = {'train': 4024, 'val': 1332, 'test': 1378}
 
 class SyntheticORDataset:
     def __init__(self, config, split='val', root='synthetic_4dor', n_frames=None, image_size=(336, 336), d_model=4096,
-                 unique_images=8, for_eval=False, shuffle_objs=False, mv_desc=False):
+                 unique_images=8, for_eval=False, shuffle_objs=False, mv_desc=False, image_format='png'):
         self.config, self.split, self.root = config, split, root
         self.classNames, self.relationNames = list(CLASS_NAMES), list(RELATION_NAMES)
         self.w_cls_obj = torch.ones(len(self.classNames))
@@ -28,6 +30,9 @@ class SyntheticORDataset:
         per = [n // len(takes) + (1 if i < n % len(takes) else 0) for i in range(len(takes))]
         self.scans = [f'{t}_{i:06d}_{split}' for t, k in zip(takes, per) for i in range(k)]
         self.image_size, self.unique_images = image_size, unique_images
+        if image_format not in ('png', 'jpg'):
+            raise ValueError(f'image_format {image_format!r}: png or jpg')
+        self.image_format = image_format
         self.d_model = d_model
         self._written = set()
         self.use_vis = bool(config.get('USE_VIS_DESC'))
@@ -42,12 +47,19 @@ class SyntheticORDataset:
 
     def _image(self, idx, cam):
         slot = (idx % self.unique_images) * 6 + cam
-        path = os.path.join(self.root, f'frame{slot:05d}_camera0{cam + 1}.png')
+        w, h = self.image_size
+        tag = '' if (w, h) == (336, 336) else f'_{w}x{h}'
+        path = os.path.join(self.root, f'frame{slot:05d}_camera0{cam + 1}{tag}.{self.image_format}')
         if path not in self._written and not os.path.exists(path):
             os.makedirs(self.root, exist_ok=True)
             rng = np.random.default_rng(1234 + slot)
-            w, h = self.image_size
-            Image.fromarray(rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)).save(path)
+            if self.image_format == 'png':
+                Image.fromarray(rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)).save(path)
+            else:
+                base = Image.fromarray(rng.integers(0, 256, size=(max(h // 64, 2), max(w // 64, 2), 3), dtype=np.uint8))
+                img = np.asarray(base.resize((w, h), Image.BICUBIC)).astype(np.int16)
+                img += rng.integers(-6, 7, size=(h, w, 1), dtype=np.int16)
+                Image.fromarray(np.clip(img, 0, 255).astype(np.uint8)).save(path, quality=90)
         self._written.add(path)
         return path
 

@@ -7,6 +7,7 @@ visual-descriptor variants, optional temporal memory), tokenise with the image p
 native generate(), decode, map symbols back to names, parse triplets, and accumulate the relation labels that
 sklearn scores per take."""
 import itertools
+import os
 import re
 from collections import defaultdict
 
@@ -30,7 +31,7 @@ MEMORY_CHAR_LIMIT = 5000
 class OracleWrapper:
     def __init__(self, config, num_class, num_rel, weights_obj, weights_rel, relationNames, model_path,
                  model_base='liuhaotian/llava-v1.5-7b', load_8bit=False, load_4bit=False, mv_desc=False,
-                 device_preprocess=True, stream=True, **engine_kw):
+                 device_preprocess=True, stream=True, decode_workers=None, **engine_kw):
         self.config = config
         self.mconfig = config['MODEL']
         self.n_object_types = 6
@@ -47,6 +48,11 @@ class OracleWrapper:
         self.mv_desc = mv_desc
         self.device_preprocess, self._preproc = device_preprocess, None
         self.stream = stream          # validate(): continuous batching across dataloader batches (identical outputs)
+        # camera images of the NEXT batches are opened + decoded by a thread pool while the GPU works on the current one
+        # (the reference decodes 4-6 x 2048x1536 JPEGs per frame serially in the main process, ..._oracle.py:60-63; Pillow's
+        # decoder releases the GIL). 0 = decode in the main thread at use, as the reference does.
+        self.decode_workers = min(8, max(1, (os.cpu_count() or 2) // 2)) if decode_workers is None else int(decode_workers)
+        self._pool = None
         self.temporal_online_prediction = config.get('temporality') == 'PRED'
         if self.temporal_online_prediction:
             print('Preparing temporality PRED')
@@ -94,8 +100,40 @@ class OracleWrapper:
         conv.append_message(conv.roles[1], None)
         return conv, conv.get_prompt()
 
+    @staticmethod
+    def _open_rgb(path):
+        return Image.open(path).convert('RGB')
+
+    def _prefetched(self, dataloader, depth=2):
+        """Yields the dataloader's batches; the camera views of the next `depth` batches are being decoded meanwhile."""
+        if self.decode_workers <= 0:
+            yield from dataloader
+            return
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=self.decode_workers, thread_name_prefix='orc-decode')
+        it = iter(dataloader)
+        ahead = []
+
+        def push():
+            try:
+                batch = next(it)
+            except StopIteration:
+                return
+            for elem in batch:
+                elem['_views'] = [self._pool.submit(self._open_rgb, elem['image_paths'][cam - 1]) for cam in self.config['CAMERAS']]
+            ahead.append(batch)
+        for _ in range(depth):
+            push()
+        while ahead:
+            batch = ahead.pop(0)
+            push()
+            yield batch
+
     def load_views(self, elem):
-        views = [Image.open(elem['image_paths'][cam - 1]).convert('RGB') for cam in self.config['CAMERAS']]
+        futures = elem.pop('_views', None)
+        views = [f.result() for f in futures] if futures is not None else \
+            [self._open_rgb(elem['image_paths'][cam - 1]) for cam in self.config['CAMERAS']]
         if (self.device_preprocess and torch.device(self.model.device).type == 'cuda' and len({v.size for v in views}) == 1
                 and getattr(self.model.config, 'image_aspect_ratio', None) == 'pad'):
             # pad + PIL-exact bicubic resize + normalisation on the device (oracle_amd/preprocess.py); same bits as
@@ -253,7 +291,7 @@ class OracleWrapper:
 
         def limited():
             left = limit
-            for batch in dataloader:
+            for batch in self._prefetched(dataloader):
                 if left is not None:
                     if left <= 0:
                         return

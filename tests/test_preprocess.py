@@ -80,3 +80,23 @@ def test_device_preprocess_is_bit_exact(h, w):
         assert torch.equal(out[i], want)
     host = process_images([Image.fromarray(v) for v in views], proc, cfg).to(torch.bfloat16)[0]
     assert torch.equal(out, host)
+
+
+@pytest.mark.gpu
+def test_device_preprocess_of_jpeg_decoded_dataset_views(tmp_path):
+    """The 4D-OR camera format: 2048 x 1536 JPEG files written by the synthetic dataset, decoded by Pillow
+    (in the wrapper's decode threads), then padded / resized / normalised on the device: identical bits to the host path
+    process_images(...).to(bfloat16) on the same decoded views."""
+    from oracle_amd.preprocess import DevicePreprocessor
+    from oracle_amd.scene_graph_prediction.scene_graph_helpers.dataset.synthetic_dataset import SyntheticORDataset
+    ds = SyntheticORDataset({}, 'val', root=str(tmp_path / 'imgs'), n_frames=2, image_size=(2048, 1536), image_format='jpg')
+    paths = ds[0]['image_paths'][:4]
+    assert all(p.endswith('.jpg') for p in paths)
+    views = [Image.open(p).convert('RGB') for p in paths]
+    assert views[0].size == (2048, 1536)
+    proc = ClipImageProcessor()
+    cfg = type('C', (), {'image_aspect_ratio': 'pad'})()
+    out = DevicePreprocessor(proc, 'cuda:0')([np.asarray(v) for v in views]).cpu()
+    host = process_images(views, proc, cfg).to(torch.bfloat16)[0]
+    assert torch.equal(out, host)
+    assert os.path.getsize(paths[0]) < 2 << 20          # image-like content: a few hundred KB, like a camera JPEG

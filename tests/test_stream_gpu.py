@@ -1,6 +1,7 @@
-"""GPU: continuous batching (generate_stream / orc_stream_begin + orc_prefill_slot + orc_read_slots): a stream of ragged
-batches through 4 row slots with refill must return, batch by batch, exactly what generate() returns for that batch alone
-(and what the CPU oracle returns): per-row cached lengths, frozen finished rows, per-row length stops."""
+"""GPU: continuous batching (generate_stream / orc_stream_begin + orc_prefill_slots + orc_stream_attach + orc_read_slots): a
+stream of ragged batches through n decode rows over the engine's 8 KV-cache slots (next batch prefilled ahead into free
+slots, finished rows re-attached) must return, batch by batch, exactly what generate() returns for that batch alone (and
+what the CPU oracle returns): per-slot cached lengths, frozen finished rows, per-row length stops."""
 import pytest
 import torch
 
@@ -40,13 +41,13 @@ def _batches(sizes, seed):
     return out
 
 
-@pytest.mark.parametrize('n_slots,chunk', [(4, 4), (8, 8), (1, 3)])
-def test_stream_equals_generate_batch_by_batch(chain, n_slots, chunk):
+@pytest.mark.parametrize('n_rows,chunk', [(4, 4), (8, 8), (1, 3), (3, 5)])
+def test_stream_equals_generate_batch_by_batch(chain, n_rows, chunk):
     from oracle import cpu_ref as cr
     from oracle_amd.dims import TINY
     st, eng, model = chain
-    items = _batches([3, 8, 1, 5, 2, 8], seed=n_slots)
-    outs = [o.cpu() for o in model.generate_stream(iter(items), max_new_tokens=40, n_slots=n_slots, chunk=chunk)]
+    items = _batches([3, 8, 1, 5, 2, 8], seed=n_rows)
+    outs = [o.cpu() for o in model.generate_stream(iter(items), max_new_tokens=40, n_rows=n_rows, chunk=chunk)]
     assert len(outs) == len(items)
     for k, (item, out) in enumerate(zip(items, outs)):
         ref = model.generate(item['input_ids'], images=item['images'], do_sample=False, use_cache=True, max_new_tokens=40).cpu()
@@ -61,7 +62,7 @@ def test_stream_length_stops_and_capacity(chain):
     st, eng, model = chain
     items = _batches([4, 4], seed=9)
     items[0]['limits'] = [1, 3, 40, 2]
-    outs = [o.cpu() for o in model.generate_stream(iter(items), max_new_tokens=40, n_slots=3, chunk=2)]
+    outs = [o.cpu() for o in model.generate_stream(iter(items), max_new_tokens=40, n_rows=3, chunk=2)]
     full = model.generate(items[0]['input_ids'], images=items[0]['images'], max_new_tokens=40).cpu()
     L = items[0]['input_ids'].shape[1]
     for b, lim in enumerate(items[0]['limits']):
@@ -69,14 +70,24 @@ def test_stream_length_stops_and_capacity(chain):
         assert torch.equal(outs[0][b, L:L + n], full[b, L:L + n])
         assert bool((outs[0][b, L + n:] == 0).all())
     assert torch.equal(outs[1], model.generate(items[1]['input_ids'], images=items[1]['images'], max_new_tokens=40).cpu())
-    # the C ABI refuses a slot outside the running batch, a stop beyond the token buffer, a prompt that cannot fit
+    # the C ABI refuses a slot outside the engine, a slot that is decoding, a stop beyond the token buffer, a prompt that cannot fit
     eng.stream_begin(2)
-    emb = torch.zeros(10, 512, dtype=torch.bfloat16, device='cuda')
+    emb = torch.zeros(1, 10, 512, dtype=torch.bfloat16, device='cuda')
+    pos = torch.arange(10, dtype=torch.int32)[None]
     with pytest.raises(_lib.OracleHipError, match='slot outside'):
-        eng.prefill_slot(2, emb, 4)
+        eng.prefill_slots([8], emb, pos, [0], [4])
     with pytest.raises(_lib.OracleHipError, match='length stop'):
-        eng.prefill_slot(0, emb, 49)
+        eng.prefill_slots([0], emb, pos, [0], [49])
     with pytest.raises(_lib.OracleHipError, match='exceeds max_seq'):
-        eng.prefill_slot(0, torch.zeros(690, 512, dtype=torch.bfloat16, device='cuda'), 20)
+        eng.prefill_slots([0], torch.zeros(1, 690, 512, dtype=torch.bfloat16, device='cuda'), torch.arange(690, dtype=torch.int32)[None], [0], [20])
+    eng.prefill_slots([5], emb, pos, [0], [4])
+    eng.stream_attach(1, 5)
+    with pytest.raises(_lib.OracleHipError, match='attached'):
+        eng.prefill_slots([5], emb, pos, [0], [4])
+    with pytest.raises(_lib.OracleHipError, match='attached to another row'):
+        eng.stream_attach(0, 5)
     with pytest.raises(_lib.OracleHipError, match='teacher forcing'):
         eng.decode_step(torch.tensor([5, 5]).cuda())
+    eng.decode_steps(6)                                                             # row 1 <- slot 5 runs to its stop of 4 tokens
+    toks, steps, unf = eng.read_slots()
+    assert steps[5] == 4 and unf[5] == 0 and len(steps) == 8

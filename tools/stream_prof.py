@@ -18,7 +18,7 @@ from oracle_amd.tokenizer import SynthTokenizer  # noqa: E402
 dev = torch.device('cuda', 0)
 state = synth.synth_state(FULL, seed=0, device=dev, device_fast=True)
 tok = SynthTokenizer(FULL.vocab)
-eng = Engine(FULL, max_batch=8, max_seq=739 + 308, max_images=24, max_new_tokens=300, pad_token_id=0, eos_token_id=-1, device=dev)
+eng = Engine(FULL, max_batch=16, max_seq=739 + 308, max_images=24, max_new_tokens=300, pad_token_id=0, eos_token_id=-1, device=dev)
 eng.load_state(state)
 del state
 model = LlavaLlamaForCausalLM(LlavaConfig(FULL, tokenizer_padding_side='left', mv_type='learned', eos_token_id=-1), eng)
@@ -43,9 +43,13 @@ _, pos, mask, _, emb, _ = prep()
 emb = emb.contiguous()
 print(f'batch prefill 8 x {emb.shape[1]}: {t(lambda: eng.prefill(emb, pos.to(torch.int32).contiguous(), [0] * 8)):.2f} ms')
 eng.stream_begin(8)
-print(f'single-row prefill T={emb.shape[1]} into a slot: {t(lambda: eng.prefill_slot(3, emb[3], 300)):.2f} ms')
-for s in range(8):
-    eng.prefill_slot(s, emb[s], 300)
+p32 = pos.to(torch.int32).contiguous()
+print(f'single-row prefill T={emb.shape[1]} into a slot: {t(lambda: eng.prefill_slots([11], emb[3:4], p32[3:4], [0], [300])):.2f} ms')
+print(f'4-row prefill into slots: {t(lambda: eng.prefill_slots([8, 9, 10, 11], emb[:4], p32[:4], [0] * 4, [300] * 4)):.2f} ms')
+print(f'8-row prefill into slots 8..15: {t(lambda: eng.prefill_slots(list(range(8, 16)), emb, p32, [0] * 8, [300] * 8)):.2f} ms')
+eng.prefill_slots(list(range(8)), emb, p32, [0] * 8, [300] * 8)
+for r in range(8):
+    eng.stream_attach(r, r)
 print(f'8 decode steps + read_slots: {t(lambda: (eng.decode_steps(8), eng.read_slots())):.2f} ms  (8 x {t(lambda: eng.decode_steps(8)) / 8:.3f} ms/step without the read)')
 one = images[:1]
 prep1 = lambda: model.prepare_inputs_labels_for_multimodal(inp['input_ids'][:1], inp['position_ids'][:1], inp['attention_mask'][:1], None, None, one, None)
