@@ -96,11 +96,50 @@ def cpu_baseline(new_tokens, views, prompt_len_spliced):
     L = 32
     per_frame = (t_clip2 / 2 * 23 * views + t_pool + (t_pre1 - t_head) * L + t_head
                  + new_tokens * ((t_dec1 - t_head) * L + t_head))
-    return {'value': 1.0 / per_frame, 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+    real = None
+    import glob
+    pts = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*', 'cpu_point.json')))
+    if pts:   # one real full-size run of configs[0] (python bench.py --cpu-point, committed): how far is this extrapolation off?
+        real = json.load(open(pts[-1]))['cpu_point']
+        real = {'source': os.path.relpath(pts[-1], ROOT), 'seconds_per_frame': real['seconds_per_frame'], 'cores': real['cores'],
+                'config': real['config'],
+                'same_method_estimate_for_that_config_s': t_clip2 / 2 * 23 + (t_pre1 - t_head) * L + t_head + 32 * ((t_dec1 - t_head) * L + t_head)}
+    return {'value': 1.0 / per_frame, 'unit': 'frames/s', 'cores': cores, 'kind': 'port', 'measured_full_size_point': real,
             'sample': (f'fp32 CPU oracle, 1 frame: CLIP 1 view x 2 layers ({t_clip2:.2f}s) scaled to {views} views x 23 layers; '
                        f'pooler+projector ({t_pool:.2f}s); 1 LLaMA layer prefill T={prompt_len_spliced} ({t_pre1:.2f}s) x32; '
                        f'1 layer decode step ({t_dec1 * 1e3:.0f}ms incl. lm_head {t_head * 1e3:.0f}ms) x32 x {new_tokens} tokens'),
             's_per_frame': per_frame}
+
+
+def cpu_point():
+    """BASELINE configs[0], timed for real (BASELINE.md 3 "the mandatory CPU point"): single-view LLaVA-1.5-7B
+    (mv_type=concat), one synthetic 336x336 frame, the plain ORacle prompt, 32-token greedy decode, through the fp32 CPU
+    oracle (oracle/cpu_ref.py) at FULL size on all host threads. Needs ~30 GB of RAM and about a minute; not part of the
+    default run (python bench.py --cpu-point)."""
+    import torch
+    from oracle import cpu_ref as cr
+    from oracle_amd import synth
+    from oracle_amd.dims import FULL
+    from oracle_amd.tokenizer import SynthTokenizer
+    torch.manual_seed(0)
+    t0 = time.perf_counter()
+    st = synth.synth_state(FULL, seed=0, dtype=torch.float32, device='cpu', device_fast=True)
+    t_w = time.perf_counter() - t0
+    ids, images = build_inputs(SynthTokenizer(FULL.vocab), 1, 1, FULL, 'cpu')
+    with torch.inference_mode():
+        t0 = time.perf_counter()
+        feats = cr.encode_image_features(st, FULL, images.float(), 'concat')
+        t_vis = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        out = cr.greedy_generate(st, FULL, ids, None, mv_type='concat', max_new_tokens=32, eos_token_id=-1, image_features=feats)
+        t_gen = time.perf_counter() - t0
+    n = out.shape[1] - ids.shape[1]
+    res = {'config': 'BASELINE configs[0]: single-view LLaVA-1.5-7B, 1 synthetic 336x336 frame, plain prompt '
+                     f'(spliced T={ids.shape[1] - 1 + 576}), {n}-token greedy decode, fp32 CPU oracle, full size',
+           'cores': torch.get_num_threads(), 'seconds_per_frame': t_vis + t_gen, 'frames_per_s': 1.0 / (t_vis + t_gen),
+           'vision_s': t_vis, 'prefill_plus_decode_s': t_gen, 'random_weight_generation_s': t_w, 'new_tokens': n}
+    print(json.dumps({'cpu_point': res}), flush=True)
+    return res
 
 
 def pmc_traffic():
@@ -259,6 +298,8 @@ def main():
                     help="'both' (default): after the uniform-length headline also run the 4D-OR answer-length distribution "
                          "(extra.ragged: batch-by-batch vs slot refill); 'uniform': headline only")
     ap.add_argument('--ragged-batches', type=int, default=8)
+    ap.add_argument('--cpu-point', action='store_true',
+                    help='time BASELINE configs[0] for real on the host cores (full-size fp32 CPU oracle, ~30 GB RAM, ~1 min) and exit')
     ap.add_argument('--dry-run', action='store_true',
                     help='launcher / rendezvous / gather / max-over-ranks plumbing only (no GPU, no engine): CPU test of the N>1 path')
     a = ap.parse_args()
@@ -271,6 +312,8 @@ def main():
 
     if a.dry_run:
         return dry_run(a)
+    if a.cpu_point:
+        return cpu_point()
 
     import torch
     import torch.distributed as dist
