@@ -563,19 +563,33 @@ extern "C" int orc_pool_views(orc_engine* e, const void* features, const int32_t
   HIPCHK(launch_layernorm(e->w_h, d, e->pool_elnw, e->pool_elnb, e->w_h, d, M, d, c.pool_eps, s));
   for (int i = 0; i < c.pool_layers; ++i) {
     const PoolLayer& L = e->pool[i];
+    // Only the first `patches` tokens of every row leave the pooler (multimodal_projector/builder.py:80 keeps [:, :576]): in
+    // the LAST layer the queries, the output projection, both LayerNorms and the MLP run on those rows only (K / V still
+    // cover all Sx tokens); the reference computes the other 2/3 of that layer at 3 views and throws it away.
+    const bool last = (i == c.pool_layers - 1) && Sx > patches;
+    const int Sq = last ? patches : Sx, Mq = B * Sq;
     ORCCHK(gemm(e->w_h, d, L.qkv, L.bqkv, nullptr, 0, e->w_qkv, 3 * d, M, EPI_NONE, s, false));
+    bf16_t* hq = e->w_h;                       // residual rows of the queries
+    if (last) {
+      HIPCHK(launch_copy_rows(e->w_h, (long)Sx * d, e->w_aux, (long)patches * d, B, patches, d, s));
+      hq = e->w_aux;
+    }
     AttnArgs a;
     a.Q = e->w_qkv; a.K = e->w_qkv + d; a.V = e->w_qkv + 2 * d;
     a.q_bs = a.k_bs = a.v_bs = (long)Sx * 3 * d; a.q_hs = a.k_hs = a.v_hs = 128; a.q_ts = a.k_ts = a.v_ts = 3 * d;
-    a.O = e->w_att; a.o_bs = (long)Sx * d; a.o_hs = 128; a.o_ts = d;
-    a.B = B; a.H = c.pool_heads; a.Sq = Sx; a.Sk = Sx; a.kbeg = nullptr; a.kend = e->d_rowvalid; a.causal = 0; a.q_off = 0;
+    a.O = e->w_att; a.o_bs = (long)Sq * d; a.o_hs = 128; a.o_ts = d;
+    a.B = B; a.H = c.pool_heads; a.Sq = Sq; a.Sk = Sx; a.kbeg = nullptr; a.kend = e->d_rowvalid; a.causal = 0; a.q_off = 0;
     a.scale = 0.08838834764831845f;   // 128^-0.5
     HIPCHK(launch_attention(a, 128, s));
-    ORCCHK(gemm(e->w_att, d, L.o, L.bo, e->w_h, d, e->w_h, d, M, EPI_RESIDUAL, s, false));
-    HIPCHK(launch_layernorm(e->w_h, d, L.ln1w, L.ln1b, e->w_h, d, M, d, c.pool_eps, s));
-    ORCCHK(gemm(e->w_h, d, L.wi, L.bi, nullptr, 0, e->w_mlp, c.pool_ff, M, EPI_GELU, s, false));
-    ORCCHK(gemm(e->w_mlp, c.pool_ff, L.wout, L.bout, e->w_h, d, e->w_h, d, M, EPI_RESIDUAL, s, false));
-    HIPCHK(launch_layernorm(e->w_h, d, L.ln2w, L.ln2b, e->w_h, d, M, d, c.pool_eps, s));
+    ORCCHK(gemm(e->w_att, d, L.o, L.bo, hq, d, hq, d, Mq, EPI_RESIDUAL, s, false));
+    HIPCHK(launch_layernorm(hq, d, L.ln1w, L.ln1b, hq, d, Mq, d, c.pool_eps, s));
+    ORCCHK(gemm(hq, d, L.wi, L.bi, nullptr, 0, e->w_mlp, c.pool_ff, Mq, EPI_GELU, s, false));
+    ORCCHK(gemm(e->w_mlp, c.pool_ff, L.wout, L.bout, hq, d, hq, d, Mq, EPI_RESIDUAL, s, false));
+    HIPCHK(launch_layernorm(hq, d, L.ln2w, L.ln2b, hq, d, Mq, d, c.pool_eps, s));
+    if (last) {
+      HIPCHK(hipMemcpyAsync(out, hq, (size_t)Mq * d * 2, hipMemcpyDeviceToDevice, s));
+      return 0;
+    }
   }
   HIPCHK(launch_copy_rows(e->w_h, (long)Sx * d, (bf16_t*)out, (long)patches * d, B, patches, d, s));
   return 0;
@@ -643,7 +657,8 @@ static int gemv_ex(orc_engine* e, const bf16_t* X, int ldx, const Packed& W, con
 }
 
 // prefill: tiled MFMA GEMMs + flash attention over all B*T positions
-// pm: batch row -> KV-cache slot the row is prefilled into
+// pm: batch row -> KV-cache slot the row is prefilled into. Leaves the final hidden state of the LAST position of every row in
+// d_h (B rows, row-major).
 static int llama_prefill_layers(orc_engine* e, bf16_t* h, bf16_t* xn, bf16_t* qkv, bf16_t* att, bf16_t* mlp, int B, int T,
                                 const int32_t* pos, hipStream_t s, const RowMap& pm) {
   const orc_config& c = e->c;
@@ -668,6 +683,18 @@ static int llama_prefill_layers(orc_engine* e, bf16_t* h, bf16_t* xn, bf16_t* qk
     a.scale = 0.08838834764831845f;
     a.kv_map_on = 1; a.kv_map = pm;
     HIPCHK(launch_attention(a, 128, s));
+    if (i == c.n_layers - 1) {
+      // Greedy search reads only the last position of every row (the reference computes logits for all T and discards them,
+      // llava_llama.py:87-98), and nothing after the last layer's K / V write depends on the other positions: its o_proj and MLP
+      // run on the B last rows only, through the decode GEMVs on the same packed weights (M = B <= 16).
+      HIPCHK(launch_copy_rows(att + (size_t)(T - 1) * d, (long)T * d, e->d_att, d, B, 1, d, s));
+      HIPCHK(launch_copy_rows(h + (size_t)(T - 1) * d, (long)T * d, e->d_h, d, B, 1, d, s));
+      ORCCHK(gemm(e->d_att, d, L.o, nullptr, e->d_h, d, e->d_h, d, B, EPI_RESIDUAL, s, true));
+      HIPCHK(launch_rmsnorm(e->d_h, d, L.ln_post, e->d_xn, d, B, d, c.rms_eps, s));
+      ORCCHK(gemm(e->d_xn, d, L.gu, nullptr, nullptr, 0, e->d_mlp, c.d_ff, B, EPI_SWIGLU, s, true));
+      ORCCHK(gemm(e->d_mlp, c.d_ff, L.down, nullptr, e->d_h, d, e->d_h, d, B, EPI_RESIDUAL, s, true));
+      break;
+    }
     ORCCHK(gemm(att, d, L.o, nullptr, h, d, h, d, M, EPI_RESIDUAL, s, false));
     HIPCHK(launch_rmsnorm(h, d, L.ln_post, xn, d, M, d, c.rms_eps, s));
     ORCCHK(gemm(xn, d, L.gu, nullptr, nullptr, 0, mlp, c.d_ff, M, EPI_SWIGLU, s, false));
@@ -769,8 +796,7 @@ static int prefill_into_slots(orc_engine* e, const int* slots, int k, const void
   const int d = c.d_model, M = k * T;
   HIPCHK(hipMemcpyAsync(e->w_h, embeds, (size_t)M * d * 2, hipMemcpyDeviceToDevice, s));
   ORCCHK(llama_prefill_layers(e, e->w_h, e->w_xn, e->w_qkv, e->w_att, e->w_mlp, k, T, position_ids, s, pm));
-  // last position of every (left-padded) row: row b*T + T-1  -> stride T*d
-  ORCCHK(head_and_sample(e, e->w_h + (size_t)(T - 1) * d, T * d, k, logits_out, false, s, pm));
+  ORCCHK(head_and_sample(e, e->d_h, d, k, logits_out, false, s, pm));   // the rows' last positions
   return 0;
 }
 
