@@ -215,22 +215,23 @@ def ragged_runs(model, input_ids, images, batch, n_batches, rank):
     """The same workload with the 4D-OR answer-length distribution instead of a uniform 150 tokens:
     (a) batch by batch through generate() -- every batch decodes until its longest answer ends (the reference's loop);
     (b) generate_stream() -- the next batch is prefilled ahead into spare KV slots and a finished row continues with a
-    waiting frame at once. Same frames, same per-frame length stops, same decode width (batch rows)."""
+    waiting frame at once; once with the same decode width (batch rows), once with 16 rows (two incoming batches side by
+    side: continuous batching decouples the decode width from the DataLoader's batch size). Same frames, same length stops."""
     import torch
     lens, d = ragged_lengths(batch * n_batches, 4242 + rank, 300)
     items = [{'input_ids': input_ids, 'images': images, 'limits': lens[i * batch:(i + 1) * batch]} for i in range(n_batches)]
     out = {'length_source': 'tests/golden/answer_lengths_4dor_val.json', 'frames': batch * n_batches,
            'mean_len': sum(lens) / len(lens), 'max_len': max(lens),
            'mean_longest_of_batch': sum(max(it['limits']) for it in items) / n_batches}
-    for name in ('batch_by_batch', 'slot_refill'):
+    for name in ('batch_by_batch', 'slot_refill', 'slot_refill_16_rows'):
         for rep in range(2):                       # first pass = warm-up
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             if name == 'batch_by_batch':
                 res = [model.generate(it['input_ids'], images=it['images'], do_sample=False, use_cache=True, max_new_tokens=300,
                                       limits=it['limits'], chunk=8) for it in items]
-            else:
-                res = list(model.generate_stream(iter(items), max_new_tokens=300, n_rows=batch, chunk=8))
+            else:   # decode width = the reference's batch, or two of its batches side by side (same tokens per frame)
+                res = list(model.generate_stream(iter(items), max_new_tokens=300, n_rows=batch if name == 'slot_refill' else 16, chunk=8))
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
         L = input_ids.shape[1]
@@ -345,7 +346,7 @@ def main():
     T = probe_ids.shape[1] - 1 + 576
     cap_new = max(a.new_tokens, 300 if a.lengths == 'both' else 16)   # the ragged leg decodes up to the reference's 300
     # KV-cache slots: the ragged leg decodes a.batch rows and prefills the next batch ahead into as many spare slots
-    n_slots = min(16, 2 * a.batch) if a.lengths == 'both' else a.batch
+    n_slots = 32 if a.lengths == 'both' else a.batch
     eng = Engine(dims, max_batch=n_slots, max_seq=T + cap_new + 8, max_images=a.batch * a.views,
                  max_new_tokens=cap_new, pad_token_id=0, eos_token_id=-1, device=dev)
     eng.load_state(state)

@@ -58,9 +58,14 @@ struct LlamaLayer {
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
-// dev_ints layout (ints): 16 header, then per-row arrays of 16 rows each, then tokens [16][max_new_tokens]
-enum { DI_UNF = 16, DI_NEXT = 32, DI_ARGMAX = 48, DI_KBEG = 64, DI_KEND = 80, DI_ROWOFF = 96, DI_ROWVALID = 112,
-       DI_CURLEN = 128, DI_ROWSTEP = 144, DI_LIMIT = 160, DI_TOKENS = 192 };
+// A launch has at most 16 ROWS (one MFMA B-operand tile in the decode GEMVs; the prefill batches the same way); the KV cache
+// and the greedy state have up to kMaxSlots SLOTS, so that frames can wait prefilled while 16 others decode.
+constexpr int kMaxRows = 16, kMaxSlots = 32;
+// dev_ints layout (ints): 16 header, per-slot state arrays of kMaxSlots each, three 16-entry per-launch-row arrays, then tokens
+// [slots][max_new_tokens]
+enum { DI_UNF = 16, DI_NEXT = DI_UNF + kMaxSlots, DI_ARGMAX = DI_NEXT + kMaxSlots, DI_KBEG = DI_ARGMAX + kMaxSlots,
+       DI_CURLEN = DI_KBEG + kMaxSlots, DI_ROWSTEP = DI_CURLEN + kMaxSlots, DI_LIMIT = DI_ROWSTEP + kMaxSlots,
+       DI_KEND = DI_LIMIT + kMaxSlots, DI_ROWOFF = DI_KEND + 16, DI_ROWVALID = DI_ROWOFF + 16, DI_TOKENS = DI_ROWVALID + 16 };
 
 }  // namespace
 
@@ -244,7 +249,7 @@ extern "C" int orc_engine_create(const orc_config* cfg, orc_engine** out) {
   if (c.n_heads <= 0 || c.d_model != c.n_heads * 128) return fail("orc_engine_create", "LLaMA head_dim must be 128");
   if (c.clip_d % c.clip_heads || c.clip_d / c.clip_heads != 64) return fail("orc_engine_create", "CLIP head_dim must be 64");
   if (c.clip_d / c.pool_heads != 128) return fail("orc_engine_create", "pooler head_dim must be 128");
-  if (c.max_batch < 1 || c.max_batch > 16) return fail("orc_engine_create", "max_batch must be in 1..16");
+  if (c.max_batch < 1 || c.max_batch > kMaxSlots) return fail("orc_engine_create", "max_batch (KV-cache slots) must be in 1..32");
   if (c.d_model % 256 || c.d_ff % 64 || c.vocab % 128 || c.clip_d % 128 || c.clip_ff % 128 || c.pool_ff % 128)
     return fail("orc_engine_create", "widths must be multiples of 128 (d_model: 256, i.e. an even head count; d_ff: 64)");
   if (c.d_model > 4096) return fail("orc_engine_create", "d_model above 4096 is not supported (decode row-scale partials: d_model / 16 <= 256)");
@@ -442,8 +447,9 @@ extern "C" int orc_engine_finalize(orc_engine* e) {
     ORCCHK(e->alloc((void**)&e->vcache, e->kv_layer_elems * c.n_layers * 2));
     const int tokens = (c.clip_image / c.clip_patch) * (c.clip_image / c.clip_patch) + 1;
     int rows = c.max_images * tokens;
-    if (c.max_batch * c.max_seq > rows) rows = c.max_batch * c.max_seq;
-    if (c.max_batch * c.pool_maxpos > rows) rows = c.max_batch * c.pool_maxpos;
+    const int max_rows = c.max_batch < kMaxRows ? c.max_batch : kMaxRows;   // rows of one prefill / pooler / decode launch
+    if (max_rows * c.max_seq > rows) rows = max_rows * c.max_seq;
+    if (max_rows * c.pool_maxpos > rows) rows = max_rows * c.pool_maxpos;
     rows = round_up(rows, 128);
     e->ws_rows = rows;
     const int wd = c.d_model > c.clip_d ? c.d_model : c.clip_d;
@@ -467,7 +473,7 @@ extern "C" int orc_engine_finalize(orc_engine* e) {
     ORCCHK(e->alloc((void**)&e->d_att, (size_t)16 * c.d_model * 2));
     ORCCHK(e->alloc((void**)&e->d_qkv, (size_t)16 * c.d_model * 3 * 2));
     ORCCHK(e->alloc((void**)&e->d_mlp, (size_t)16 * c.d_ff * 2));
-    const size_t nint = DI_TOKENS + (size_t)16 * c.max_new_tokens;
+    const size_t nint = DI_TOKENS + (size_t)kMaxSlots * c.max_new_tokens;
     ORCCHK(e->alloc((void**)&e->dev_ints, nint * 4));
     HIPCHK(hipMemset(e->dev_ints, 0, nint * 4));
     int* di = e->dev_ints;
@@ -541,7 +547,7 @@ extern "C" int orc_pool_views(orc_engine* e, const void* features, const int32_t
   const orc_config& c = e->c;
   hipStream_t s = S(stream);
   const int G = c.clip_image / c.clip_patch, patches = G * G, d = c.clip_d;
-  if (B < 1 || B > c.max_batch) return fail("orc_pool_views", "batch outside 1..max_batch");
+  if (B < 1 || B > c.max_batch || B > kMaxRows) return fail("orc_pool_views", "batch outside 1..min(max_batch, 16)");
   int vmax = 0, off = 0;
   int* hp = e->h_pinned;
   HIPCHK(hipStreamSynchronize(s));   // pinned staging reuse
@@ -771,7 +777,7 @@ static int head_and_sample(orc_engine* e, const bf16_t* hrows, int ldh, int B, f
 static int prefill_into_slots(orc_engine* e, const int* slots, int k, const void* embeds, const int32_t* position_ids,
                               const int32_t* left_pad, const int32_t* limits, int T, float* logits_out, hipStream_t s, const char* who) {
   const orc_config& c = e->c;
-  if (k < 1 || k > c.max_batch) return fail(who, "row count outside 1..max_batch");
+  if (k < 1 || k > c.max_batch || k > kMaxRows) return fail(who, "row count outside 1..min(max_batch, 16)");
   if (T < 1 || T >= c.max_seq) return fail(who, "prompt length exceeds max_seq");
   if ((long)k * T > e->ws_rows) return fail(who, "rows*T exceeds workspace");
   SlotInitArgs in = {};
@@ -804,7 +810,7 @@ extern "C" int orc_prefill(orc_engine* e, const void* embeds, const int32_t* pos
                            int B, int T, float* logits_out, void* stream) {
   if (!e || !e->finalized) return fail("orc_prefill", "engine not finalized");
   hipStream_t s = S(stream);
-  if (B < 1 || B > e->c.max_batch) return fail("orc_prefill", "batch outside 1..max_batch");
+  if (B < 1 || B > e->c.max_batch || B > kMaxRows) return fail("orc_prefill", "batch outside 1..min(max_batch, 16)");
   int slots[16];
   for (int i = 0; i < 16; ++i) {
     slots[i] = i;
@@ -891,7 +897,7 @@ extern "C" int orc_set_row_limits(orc_engine* e, const int32_t* limits_host, int
 // ---------------------------------------------------------------------------- continuous batching
 extern "C" int orc_stream_begin(orc_engine* e, int n_rows, void* stream) {
   if (!e || !e->finalized) return fail("orc_stream_begin", "engine not finalized");
-  if (n_rows < 1 || n_rows > e->c.max_batch) return fail("orc_stream_begin", "n_rows outside 1..max_batch");
+  if (n_rows < 1 || n_rows > e->c.max_batch || n_rows > kMaxRows) return fail("orc_stream_begin", "n_rows outside 1..min(max_batch, 16)");
   hipStream_t s = S(stream);
   e->stream_mode = true;
   e->cur_batch = n_rows;

@@ -41,6 +41,8 @@ class OracleWrapper:
         self.lr = float(config['LR']) if 'LR' in config else 0.0
         self.reset_metrics()
         self.model_name = get_model_name_from_path(model_path)
+        if config.get('temporality') == 'PRED':
+            engine_kw.setdefault('max_batch', 2)      # online temporal: one frame at a time (main.py:58-61), no spare KV slots
         self.tokenizer, self.model, self.image_processor, self.context_len = load_pretrained_model(
             model_path, model_base, self.model_name, load_8bit, load_4bit, **engine_kw)
         self.model.config.mv_type = self.mconfig['mv_type']

@@ -91,3 +91,24 @@ def test_stream_length_stops_and_capacity(chain):
     eng.decode_steps(6)                                                             # row 1 <- slot 5 runs to its stop of 4 tokens
     toks, steps, unf = eng.read_slots()
     assert steps[5] == 4 and unf[5] == 0 and len(steps) == 8
+
+
+def test_stream_16_rows_over_32_slots_equals_generate():
+    """Decode width 16 over 32 KV-cache slots (two of the reference's batches of 8 decode side by side, the next two wait
+    prefilled): still exactly generate()'s tokens for every incoming batch."""
+    from oracle_amd.dims import TINY
+    from oracle_amd.engine import Engine
+    from oracle_amd.llava.model.language_model.llava_llama import LlavaConfig, LlavaLlamaForCausalLM
+    from oracle_amd.synth import install_chain, synth_state
+    st = install_chain(synth_state(TINY, seed=0), TINY)
+    eng = Engine(TINY, max_batch=32, max_seq=700, max_images=80, max_new_tokens=48)
+    eng.load_state(st)
+    model = LlavaLlamaForCausalLM(LlavaConfig(TINY, tokenizer_padding_side='left'), eng)
+    items = _batches([8, 8, 8, 5, 8, 3, 8], seed=21)
+    outs = [o.cpu() for o in model.generate_stream(iter(items), max_new_tokens=40, chunk=4)]          # default width: 16 rows
+    refs = [model.generate(it['input_ids'], images=it['images'], max_new_tokens=40).cpu() for it in items]
+    for k, (o, r) in enumerate(zip(outs, refs)):
+        assert torch.equal(o, r), k
+    with pytest.raises(Exception, match='16'):
+        model.generate(torch.cat([items[0]['input_ids']] * 3), images=torch.cat([items[0]['images']] * 3), max_new_tokens=4)
+    eng.close()
