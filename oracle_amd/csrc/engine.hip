@@ -111,7 +111,6 @@ struct orc_engine {
   int* d_pfkbeg = nullptr;   // [16] left pad of the rows of the prefill being launched (attention reads it per launch row)
   bool stream_mode = false;  // continuous batching (orc_stream_begin): decode rows are re-pointed at slots prefilled ahead
   RowMap row_map;            // decode row -> slot (host copy; goes to the kernels by value)
-  int* h_pinned = nullptr;   // pinned host staging (small int arrays)
   int cur_batch = 0, cur_T = 0;
   int steps_issued = 0;   // decode steps enqueued since the last prefill (host-side mirror of the device cur_len - T)
   // sampled HIP-event timing of the dominant decode kernel (gate/up GEMV), see orc_profile_*
@@ -266,7 +265,6 @@ extern "C" void orc_engine_destroy(orc_engine* e) {
   (void)hipDeviceSynchronize();
   for (void* p : e->owned)
     if (p) (void)hipFree(p);
-  if (e->h_pinned) (void)hipHostFree(e->h_pinned);
   delete e;
 }
 
@@ -485,7 +483,6 @@ extern "C" int orc_engine_finalize(orc_engine* e) {
     e->d_tokens = di + DI_TOKENS;
     e->d_pfkbeg = di + DI_KEND;   // (the pooler's key-end array is not used by a LLaMA prefill)
     e->row_map = identity_map();
-    HIPCHK(hipHostMalloc((void**)&e->h_pinned, 4096, hipHostMallocDefault));
   }
   HIPCHK(hipDeviceSynchronize());
   e->finalized = true;
@@ -549,20 +546,20 @@ extern "C" int orc_pool_views(orc_engine* e, const void* features, const int32_t
   const int G = c.clip_image / c.clip_patch, patches = G * G, d = c.clip_d;
   if (B < 1 || B > c.max_batch || B > kMaxRows) return fail("orc_pool_views", "batch outside 1..min(max_batch, 16)");
   int vmax = 0, off = 0;
-  int* hp = e->h_pinned;
-  HIPCHK(hipStreamSynchronize(s));   // pinned staging reuse
+  ScatterArgs ro = {}, rv = {};   // per-row feature offset / valid length go to the device by value (no host staging, no sync)
+  ro.n = rv.n = B; ro.dst = e->d_rowoff; rv.dst = e->d_rowvalid;
   for (int b = 0; b < B; ++b) {
     if (views[b] < 1) return fail("orc_pool_views", "a row has no views");
-    hp[b] = off * patches;
-    hp[16 + b] = views[b] * patches;
+    ro.val[b] = off * patches;
+    rv.val[b] = views[b] * patches;
     off += views[b];
     if (views[b] > vmax) vmax = views[b];
   }
   const int Sx = vmax * patches;
   if (Sx > c.pool_maxpos) return fail("orc_pool_views", "views*patches exceeds the pooler's max_position_embeddings");
   if (off > c.max_images) return fail("orc_pool_views", "too many images");
-  HIPCHK(hipMemcpyAsync(e->d_rowoff, hp, 16 * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(e->d_rowvalid, hp + 16, 16 * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(launch_scatter_ints(ro, s));
+  HIPCHK(launch_scatter_ints(rv, s));
   const int M = B * Sx;
   HIPCHK(launch_bert_embed((const bf16_t*)features, e->d_rowoff, e->d_rowvalid, e->pool_tt0, e->pool_pos, nullptr, nullptr,
                            e->w_h, B, Sx, d, 0.f, s));

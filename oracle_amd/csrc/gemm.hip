@@ -13,6 +13,7 @@
 // Epilogues reproduce the rounding points of the reference's eager bf16 graph (each torch op rounds its
 // output to bf16): Linear -> [QuickGELU | GELU(erf) | + residual | SiLU(gate) * up] -> bf16.
 #include <map>
+#include <mutex>
 #include <utility>
 #include <vector>
 #include "common.h"
@@ -20,7 +21,7 @@
 
 namespace {
 
-int g_gemm_force = 0;   // tools: 0 auto, 1 = 128^2 register-staged kernel, 2 / 3 = DMA kernel with BM 256 / 128
+thread_local int g_gemm_force = 0;   // per thread (a test hook on one thread cannot change another engine's launches). tools: 0 auto, 1 = 128^2 register-staged kernel, 2 / 3 = DMA kernel with BM 256 / 128
 
 // fp32 sigmoid on the hardware exp / rcp (about 1 ulp each): every use rounds the result to bf16 right away
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
@@ -452,7 +453,9 @@ static long greedy_makespan(long n_tall, long n_short) {
 }
 
 static int plan_tall_tiles(int M, int N) {
-  static std::map<std::pair<int, int>, int> cache;   // launches come from one host thread per process
+  static std::map<std::pair<int, int>, int> cache;   // shared by every engine of the process: guarded
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
   auto it = cache.find({M, N});
   if (it != cache.end()) return it->second;
   const int NT = N / 256, max_tall = (M + 255) / 256;
