@@ -215,15 +215,16 @@ def ragged_runs(model, input_ids, images, batch, n_batches, rank):
     """The same workload with the 4D-OR answer-length distribution instead of a uniform 150 tokens:
     (a) batch by batch through generate() -- every batch decodes until its longest answer ends (the reference's loop);
     (b) generate_stream() -- the next batch is prefilled ahead into spare KV slots and a finished row continues with a
-    waiting frame at once; once with the same decode width (batch rows), once with 16 rows (two incoming batches side by
-    side: continuous batching decouples the decode width from the DataLoader's batch size). Same frames, same length stops."""
+    waiting frame at once; once with the same decode width (batch rows), once with 16 and once with 32 rows (two / four incoming
+    batches side by side: continuous batching decouples the decode width from the DataLoader's batch size). Same frames, same length stops."""
     import torch
     lens, d = ragged_lengths(batch * n_batches, 4242 + rank, 300)
     items = [{'input_ids': input_ids, 'images': images, 'limits': lens[i * batch:(i + 1) * batch]} for i in range(n_batches)]
     out = {'length_source': 'tests/golden/answer_lengths_4dor_val.json', 'frames': batch * n_batches,
            'mean_len': sum(lens) / len(lens), 'max_len': max(lens),
            'mean_longest_of_batch': sum(max(it['limits']) for it in items) / n_batches}
-    for name in ('batch_by_batch', 'slot_refill', 'slot_refill_16_rows'):
+    widths = {'slot_refill': batch, 'slot_refill_16_rows': 16, 'slot_refill_32_rows': 32}
+    for name in ('batch_by_batch', 'slot_refill', 'slot_refill_16_rows', 'slot_refill_32_rows'):
         for rep in range(2):                       # first pass = warm-up
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -231,7 +232,7 @@ def ragged_runs(model, input_ids, images, batch, n_batches, rank):
                 res = [model.generate(it['input_ids'], images=it['images'], do_sample=False, use_cache=True, max_new_tokens=300,
                                       limits=it['limits'], chunk=8) for it in items]
             else:   # decode width = the reference's batch, or two of its batches side by side (same tokens per frame)
-                res = list(model.generate_stream(iter(items), max_new_tokens=300, n_rows=batch if name == 'slot_refill' else 16, chunk=8))
+                res = list(model.generate_stream(iter(items), max_new_tokens=300, n_rows=widths[name], chunk=8))
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
         L = input_ids.shape[1]
@@ -298,7 +299,7 @@ def main():
     ap.add_argument('--lengths', default='both', choices=['uniform', 'both'],
                     help="'both' (default): after the uniform-length headline also run the 4D-OR answer-length distribution "
                          "(extra.ragged: batch-by-batch vs slot refill); 'uniform': headline only")
-    ap.add_argument('--ragged-batches', type=int, default=8)
+    ap.add_argument('--ragged-batches', type=int, default=16)
     ap.add_argument('--cpu-point', action='store_true',
                     help='time BASELINE configs[0] for real on the host cores (full-size fp32 CPU oracle, ~30 GB RAM, ~1 min) and exit')
     ap.add_argument('--dry-run', action='store_true',
@@ -346,7 +347,7 @@ def main():
     T = probe_ids.shape[1] - 1 + 576
     cap_new = max(a.new_tokens, 300 if a.lengths == 'both' else 16)   # the ragged leg decodes up to the reference's 300
     # KV-cache slots: the ragged leg decodes a.batch rows and prefills the next batch ahead into as many spare slots
-    n_slots = 32 if a.lengths == 'both' else a.batch
+    n_slots = 64 if a.lengths == 'both' else a.batch
     eng = Engine(dims, max_batch=n_slots, max_seq=T + cap_new + 8, max_images=a.batch * a.views,
                  max_new_tokens=cap_new, pad_token_id=0, eos_token_id=-1, device=dev)
     eng.load_state(state)

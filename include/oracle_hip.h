@@ -32,7 +32,7 @@ typedef struct orc_config {
   int32_t pool_layers, pool_heads, pool_ff, pool_maxpos;
   float pool_eps;
   /* capacities */
-  int32_t max_batch;      /* KV-cache slots (<= 32); one prefill / decode launch runs over at most 16 of them (rows) */
+  int32_t max_batch;      /* KV-cache slots (<= 64); one prefill / decode launch runs over at most 32 of them (rows) */
   int32_t max_seq;        /* KV-cache slots per row: spliced prompt + new tokens */
   int32_t max_images;     /* images per vision call */
   int32_t max_new_tokens; /* capacity of the on-device generated-token buffer */
@@ -124,7 +124,7 @@ int orc_set_row_limits(orc_engine* e, const int32_t* limits_host, int n, void* s
  * scene_graph_prediction_model_oracle.py:251-260): frames are independent, so a decode row whose frame has finished (EOS or
  * its length stop) takes over the next frame while the other rows keep decoding. The engine has max_batch KV-cache SLOTS,
  * each with its own greedy state on the device (cached length, left pad, step counter, length stop, unfinished flag,
- * next token, token buffer); a decode launch runs over n_rows ROWS (n_rows <= min(max_batch, 16)), each attached to one slot.
+ * next token, token buffer); a decode launch runs over n_rows ROWS (n_rows <= min(max_batch, 32)), each attached to one slot.
  *   orc_stream_begin   n_rows decode rows, none attached.
  *   orc_prefill_slots  LlavaLlamaForCausalLM.forward step 0 (llava_llama.py:54-100) for n left-padded rows (embeds
  *                      (n, T, d_model), position_ids (n*T) device, left_pad_host[n]) into the UNATTACHED slots

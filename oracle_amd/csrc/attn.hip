@@ -259,7 +259,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_attn_kernel(DecodeAttnArgs 
   if (sl < 0 || (a.unfinished && !a.unfinished[sl])) {   // inactive or finished row (its tokens are pad): no cache read at all
     if (tid < 128) {
       if (nsplit == 1) {
-        a.O[a.o_xf ? xf_off(b, h * 128 + tid) : (size_t)b * a.o_bs + h * 128 + tid] = 0;
+        a.O[a.o_xf ? xf_off_rows(b, h * 128 + tid, a.H * 128) : (size_t)b * a.o_bs + h * 128 + tid] = 0;
       } else {
         float* pp = a.part + (((size_t)b * a.H + h) * DECODE_NSPLIT + sp) * 130;
         if (tid == 0) { pp[0] = -INFINITY; pp[1] = 0.f; }
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(WAVES * 64) void decode_attn_kernel(DecodeAttnArgs 
       av += sh_acc[i][tid] * sc;
     }
     if (nsplit == 1) {
-      a.O[a.o_xf ? xf_off(b, h * 128 + tid) : (size_t)b * a.o_bs + h * 128 + tid] = f2bf(ll > 0.f ? av / ll : 0.f);
+      a.O[a.o_xf ? xf_off_rows(b, h * 128 + tid, a.H * 128) : (size_t)b * a.o_bs + h * 128 + tid] = f2bf(ll > 0.f ? av / ll : 0.f);
     } else {
       float* pp = a.part + (((size_t)b * a.H + h) * DECODE_NSPLIT + sp) * 130;
       if (tid == 0) { pp[0] = mm; pp[1] = ll; }
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(128) void decode_attn_combine_kernel(DecodeAttnArgs
     ll += pp[i * 130 + 1] * sc;
     av += pp[i * 130 + 2 + tid] * sc;
   }
-  a.O[a.o_xf ? xf_off(b, h * 128 + tid) : (size_t)b * a.o_bs + h * 128 + tid] = f2bf(ll > 0.f ? av / ll : 0.f);
+  a.O[a.o_xf ? xf_off_rows(b, h * 128 + tid, a.H * 128) : (size_t)b * a.o_bs + h * 128 + tid] = f2bf(ll > 0.f ? av / ll : 0.f);
 }
 
 }  // namespace

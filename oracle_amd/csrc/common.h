@@ -62,3 +62,7 @@ __host__ __device__ __forceinline__ size_t packed_block_elems() { return 512; }
 // elements at k = 32 kt + 8 g) is then ONE contiguous 1-KiB wave read (8 whole 128-B lines) instead of 16 half lines of
 // 16 different rows; every GEMV workgroup re-reads the whole activation through L2, so this halves its request count.
 __host__ __device__ __forceinline__ size_t xf_off(int b, int k) { return ((size_t)(k >> 3) * 16 + b) * 8 + (k & 7); }
+// more than 16 rows: one such 16-row image per group of 16 rows, images row_len * 16 elements apart
+__host__ __device__ __forceinline__ size_t xf_off_rows(int b, int k, int row_len) {
+  return (size_t)(b >> 4) * 16 * row_len + xf_off(b & 15, k);
+}

@@ -58,14 +58,15 @@ struct LlamaLayer {
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
-// A launch has at most 16 ROWS (one MFMA B-operand tile in the decode GEMVs; the prefill batches the same way); the KV cache
-// and the greedy state have up to kMaxSlots SLOTS, so that frames can wait prefilled while 16 others decode.
-constexpr int kMaxRows = 16, kMaxSlots = 32;
-// dev_ints layout (ints): 16 header, per-slot state arrays of kMaxSlots each, three 16-entry per-launch-row arrays, then tokens
-// [slots][max_new_tokens]
+// A launch has at most kMaxRows = 32 ROWS (two MFMA B-operand tiles of 16 in the decode GEMVs; the prefill batches the same
+// way); the KV cache and the greedy state have up to kMaxSlots SLOTS, so that frames can wait prefilled while others decode.
+constexpr int kMaxSlots = 64;
+// dev_ints layout (ints): 16 header, per-slot state arrays of kMaxSlots each, three per-launch-row arrays of kMaxRows, then
+// tokens [slots][max_new_tokens]
 enum { DI_UNF = 16, DI_NEXT = DI_UNF + kMaxSlots, DI_ARGMAX = DI_NEXT + kMaxSlots, DI_KBEG = DI_ARGMAX + kMaxSlots,
        DI_CURLEN = DI_KBEG + kMaxSlots, DI_ROWSTEP = DI_CURLEN + kMaxSlots, DI_LIMIT = DI_ROWSTEP + kMaxSlots,
-       DI_KEND = DI_LIMIT + kMaxSlots, DI_ROWOFF = DI_KEND + 16, DI_ROWVALID = DI_ROWOFF + 16, DI_TOKENS = DI_ROWVALID + 16 };
+       DI_KEND = DI_LIMIT + kMaxSlots, DI_ROWOFF = DI_KEND + kMaxRows, DI_ROWVALID = DI_ROWOFF + kMaxRows,
+       DI_TOKENS = DI_ROWVALID + kMaxRows };
 
 }  // namespace
 
@@ -248,7 +249,7 @@ extern "C" int orc_engine_create(const orc_config* cfg, orc_engine** out) {
   if (c.n_heads <= 0 || c.d_model != c.n_heads * 128) return fail("orc_engine_create", "LLaMA head_dim must be 128");
   if (c.clip_d % c.clip_heads || c.clip_d / c.clip_heads != 64) return fail("orc_engine_create", "CLIP head_dim must be 64");
   if (c.clip_d / c.pool_heads != 128) return fail("orc_engine_create", "pooler head_dim must be 128");
-  if (c.max_batch < 1 || c.max_batch > kMaxSlots) return fail("orc_engine_create", "max_batch (KV-cache slots) must be in 1..32");
+  if (c.max_batch < 1 || c.max_batch > kMaxSlots) return fail("orc_engine_create", "max_batch (KV-cache slots) must be in 1..64");
   if (c.d_model % 256 || c.d_ff % 64 || c.vocab % 128 || c.clip_d % 128 || c.clip_ff % 128 || c.pool_ff % 128)
     return fail("orc_engine_create", "widths must be multiples of 128 (d_model: 256, i.e. an even head count; d_ff: 64)");
   if (c.d_model > 4096) return fail("orc_engine_create", "d_model above 4096 is not supported (decode row-scale partials: d_model / 16 <= 256)");
@@ -461,16 +462,16 @@ extern "C" int orc_engine_finalize(orc_engine* e) {
     ORCCHK(e->alloc((void**)&e->w_aux, (size_t)rows * wd * 2));
     ORCCHK(e->alloc((void**)&e->w_qkv, (size_t)rows * wd * 3 * 2));
     ORCCHK(e->alloc((void**)&e->w_mlp, (size_t)rows * wm * 2));
-    ORCCHK(e->alloc((void**)&e->w_logits, (size_t)16 * c.vocab * 4));
-    ORCCHK(e->alloc((void**)&e->w_part, (size_t)16 * c.n_heads * DECODE_NSPLIT * 130 * 4));
-    ORCCHK(e->alloc((void**)&e->d_ssq, (size_t)16 * (c.d_model / 16) * 4));
-    ORCCHK(e->alloc((void**)&e->d_h, (size_t)16 * c.d_model * 2));
-    ORCCHK(e->alloc((void**)&e->d_hxf, (size_t)16 * c.d_model * 2));
-    HIPCHK(hipMemset(e->d_hxf, 0, (size_t)16 * c.d_model * 2));
-    ORCCHK(e->alloc((void**)&e->d_xn, (size_t)16 * c.d_model * 2));
-    ORCCHK(e->alloc((void**)&e->d_att, (size_t)16 * c.d_model * 2));
-    ORCCHK(e->alloc((void**)&e->d_qkv, (size_t)16 * c.d_model * 3 * 2));
-    ORCCHK(e->alloc((void**)&e->d_mlp, (size_t)16 * c.d_ff * 2));
+    ORCCHK(e->alloc((void**)&e->w_logits, (size_t)kMaxRows * c.vocab * 4));
+    ORCCHK(e->alloc((void**)&e->w_part, (size_t)kMaxRows * c.n_heads * DECODE_NSPLIT * 130 * 4));
+    ORCCHK(e->alloc((void**)&e->d_ssq, (size_t)kMaxRows * (c.d_model / 16) * 4));
+    ORCCHK(e->alloc((void**)&e->d_h, (size_t)kMaxRows * c.d_model * 2));
+    ORCCHK(e->alloc((void**)&e->d_hxf, (size_t)kMaxRows * c.d_model * 2));
+    HIPCHK(hipMemset(e->d_hxf, 0, (size_t)kMaxRows * c.d_model * 2));
+    ORCCHK(e->alloc((void**)&e->d_xn, (size_t)kMaxRows * c.d_model * 2));
+    ORCCHK(e->alloc((void**)&e->d_att, (size_t)kMaxRows * c.d_model * 2));
+    ORCCHK(e->alloc((void**)&e->d_qkv, (size_t)kMaxRows * c.d_model * 3 * 2));
+    ORCCHK(e->alloc((void**)&e->d_mlp, (size_t)kMaxRows * c.d_ff * 2));
     const size_t nint = DI_TOKENS + (size_t)kMaxSlots * c.max_new_tokens;
     ORCCHK(e->alloc((void**)&e->dev_ints, nint * 4));
     HIPCHK(hipMemset(e->dev_ints, 0, nint * 4));
@@ -544,7 +545,7 @@ extern "C" int orc_pool_views(orc_engine* e, const void* features, const int32_t
   const orc_config& c = e->c;
   hipStream_t s = S(stream);
   const int G = c.clip_image / c.clip_patch, patches = G * G, d = c.clip_d;
-  if (B < 1 || B > c.max_batch || B > kMaxRows) return fail("orc_pool_views", "batch outside 1..min(max_batch, 16)");
+  if (B < 1 || B > c.max_batch || B > kMaxRows) return fail("orc_pool_views", "batch outside 1..min(max_batch, 32)");
   int vmax = 0, off = 0;
   ScatterArgs ro = {}, rv = {};   // per-row feature offset / valid length go to the device by value (no host staging, no sync)
   ro.n = rv.n = B; ro.dst = e->d_rowoff; rv.dst = e->d_rowvalid;
@@ -689,7 +690,7 @@ static int llama_prefill_layers(orc_engine* e, bf16_t* h, bf16_t* xn, bf16_t* qk
     if (i == c.n_layers - 1) {
       // Greedy search reads only the last position of every row (the reference computes logits for all T and discards them,
       // llava_llama.py:87-98), and nothing after the last layer's K / V write depends on the other positions: its o_proj and MLP
-      // run on the B last rows only, through the decode GEMVs on the same packed weights (M = B <= 16).
+      // run on the B last rows only, through the decode GEMVs on the same packed weights (M = B <= 32).
       HIPCHK(launch_copy_rows(att + (size_t)(T - 1) * d, (long)T * d, e->d_att, d, B, 1, d, s));
       HIPCHK(launch_copy_rows(h + (size_t)(T - 1) * d, (long)T * d, e->d_h, d, B, 1, d, s));
       ORCCHK(gemm(e->d_att, d, L.o, nullptr, e->d_h, d, e->d_h, d, B, EPI_RESIDUAL, s, true));
@@ -774,12 +775,12 @@ static int head_and_sample(orc_engine* e, const bf16_t* hrows, int ldh, int B, f
 static int prefill_into_slots(orc_engine* e, const int* slots, int k, const void* embeds, const int32_t* position_ids,
                               const int32_t* left_pad, const int32_t* limits, int T, float* logits_out, hipStream_t s, const char* who) {
   const orc_config& c = e->c;
-  if (k < 1 || k > c.max_batch || k > kMaxRows) return fail(who, "row count outside 1..min(max_batch, 16)");
+  if (k < 1 || k > c.max_batch || k > kMaxRows) return fail(who, "row count outside 1..min(max_batch, 32)");
   if (T < 1 || T >= c.max_seq) return fail(who, "prompt length exceeds max_seq");
   if ((long)k * T > e->ws_rows) return fail(who, "rows*T exceeds workspace");
   SlotInitArgs in = {};
   RowMap pm;
-  for (int i = 0; i < 16; ++i) pm.slot[i] = -1;
+  for (int i = 0; i < kMaxRows; ++i) pm.slot[i] = -1;
   for (int i = 0; i < k; ++i) {
     if (slots[i] < 0 || slots[i] >= c.max_batch) return fail(who, "slot outside 0..max_batch-1");
     for (int j = 0; j < i; ++j)
@@ -807,9 +808,9 @@ extern "C" int orc_prefill(orc_engine* e, const void* embeds, const int32_t* pos
                            int B, int T, float* logits_out, void* stream) {
   if (!e || !e->finalized) return fail("orc_prefill", "engine not finalized");
   hipStream_t s = S(stream);
-  if (B < 1 || B > e->c.max_batch || B > kMaxRows) return fail("orc_prefill", "batch outside 1..min(max_batch, 16)");
-  int slots[16];
-  for (int i = 0; i < 16; ++i) {
+  if (B < 1 || B > e->c.max_batch || B > kMaxRows) return fail("orc_prefill", "batch outside 1..min(max_batch, 32)");
+  int slots[kMaxRows];
+  for (int i = 0; i < kMaxRows; ++i) {
     slots[i] = i;
     e->row_map.slot[i] = i < B ? i : -1;   // decode row b <-> slot b
   }
@@ -894,13 +895,13 @@ extern "C" int orc_set_row_limits(orc_engine* e, const int32_t* limits_host, int
 // ---------------------------------------------------------------------------- continuous batching
 extern "C" int orc_stream_begin(orc_engine* e, int n_rows, void* stream) {
   if (!e || !e->finalized) return fail("orc_stream_begin", "engine not finalized");
-  if (n_rows < 1 || n_rows > e->c.max_batch || n_rows > kMaxRows) return fail("orc_stream_begin", "n_rows outside 1..min(max_batch, 16)");
+  if (n_rows < 1 || n_rows > e->c.max_batch || n_rows > kMaxRows) return fail("orc_stream_begin", "n_rows outside 1..min(max_batch, 32)");
   hipStream_t s = S(stream);
   e->stream_mode = true;
   e->cur_batch = n_rows;
   e->cur_T = 0;
   e->steps_issued = 0;
-  for (int i = 0; i < 16; ++i) e->row_map.slot[i] = -1;   // no decode row is attached to a slot yet
+  for (int i = 0; i < kMaxRows; ++i) e->row_map.slot[i] = -1;   // no decode row is attached to a slot yet
   HIPCHK(hipMemsetAsync(e->dev_ints, 0, DI_TOKENS * 4, s));
   return 0;
 }
@@ -910,7 +911,7 @@ extern "C" int orc_prefill_slots(orc_engine* e, const int32_t* slots_host, int n
   if (!e || !e->finalized) return fail("orc_prefill_slots", "engine not finalized");
   if (!e->stream_mode) return fail("orc_prefill_slots", "call orc_stream_begin first");
   if (!slots_host || !embeds || !position_ids || !left_pad_host || !limits_host) return fail("orc_prefill_slots", "null argument");
-  for (int i = 0; i < n && i < 16; ++i)
+  for (int i = 0; i < n && i < kMaxRows; ++i)
     for (int r = 0; r < e->cur_batch; ++r)
       if (e->row_map.slot[r] == slots_host[i]) return fail("orc_prefill_slots", "slot is attached to a decode row");
   return prefill_into_slots(e, slots_host, n, embeds, position_ids, left_pad_host, limits_host, T, logits_out, S(stream), "orc_prefill_slots");
@@ -1040,23 +1041,23 @@ extern "C" int orc_test_attention(const void* q, const void* k, const void* v, i
 extern "C" int orc_test_decode_attention(const void* q, const void* kcache, const void* vcache, int B, int H, int Tmax,
                                          const int32_t* kbeg, int n_keys, void* out, void* stream) {
   if (!q || !kcache || !vcache || !out) return fail("orc_test_decode_attention", "null argument");
-  if (B < 1 || B > 16 || H < 1 || Tmax < 1 || n_keys < 1 || n_keys > Tmax) return fail("orc_test_decode_attention", "bad size");
+  if (B < 1 || B > kMaxRows || H < 1 || Tmax < 1 || n_keys < 1 || n_keys > Tmax) return fail("orc_test_decode_attention", "bad size");
   hipStream_t s = S(stream);
   float* part = nullptr;
   int* ints = nullptr;
   HIPCHK(hipMalloc((void**)&part, (size_t)B * H * DECODE_NSPLIT * 130 * 4));
-  HIPCHK(hipMalloc((void**)&ints, 32 * 4));
-  int host[32] = {0};
-  for (int b = 0; b < 16; ++b) host[b] = n_keys;
+  HIPCHK(hipMalloc((void**)&ints, 64 * 4));
+  int host[64] = {0};
+  for (int b = 0; b < 32; ++b) host[b] = n_keys;
   HIPCHK(hipMemcpyAsync(ints, host, sizeof(host), hipMemcpyHostToDevice, s));
-  if (kbeg) HIPCHK(hipMemcpyAsync(ints + 16, kbeg, B * 4, hipMemcpyDeviceToDevice, s));
+  if (kbeg) HIPCHK(hipMemcpyAsync(ints + 32, kbeg, B * 4, hipMemcpyDeviceToDevice, s));
   DecodeAttnArgs a;
   a.o_xf = 0;
   a.unfinished = nullptr;
   a.map = identity_map();
   a.Q = (const bf16_t*)q; a.q_bs = (long)H * 128; a.Kc = (const bf16_t*)kcache; a.Vc = (const bf16_t*)vcache;
   a.c_hs = (long)Tmax * 128; a.c_bs = a.c_hs * H; a.O = (bf16_t*)out; a.o_bs = (long)H * 128;
-  a.part = part; a.kbeg = ints + 16; a.cur_len = ints; a.B = B; a.H = H; a.scale = 0.08838834764831845f;
+  a.part = part; a.kbeg = ints + 32; a.cur_len = ints; a.B = B; a.H = H; a.scale = 0.08838834764831845f;
   hipError_t err = launch_decode_attention(a, s);
   hipError_t err2 = hipStreamSynchronize(s);
   (void)hipFree(part);

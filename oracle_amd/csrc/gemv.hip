@@ -1,4 +1,4 @@
-// Decode-time skinny GEMM: Y[b][n] = epilogue( sum_k X'[b][k] * W[n][k] ), 1 <= M=B <= 16 rows.
+// Decode-time skinny GEMM: Y[b][n] = epilogue( sum_k X'[b][k] * W[n][k] ), 1 <= M=B <= 32 rows (16 per MFMA B tile).
 // This is the HBM-bound heart of KV-cached greedy decode (13.2 GB of bf16 weights streamed per step,
 // shared by all rows of the batch). One workgroup = WAVES waves owns NT n-tiles of 16 weight rows and splits K
 // WAVES ways; every wave streams its 1-KiB packed blocks straight from HBM into VGPRs with non-temporal 16-byte
@@ -23,179 +23,214 @@ namespace {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Rows: the MFMA B operand holds 16 batch rows; with RH = 2 "row halves" a workgroup multiplies every weight fragment it has
+// loaded by TWO B fragments (rows 0..15 and 16..31), so up to 32 rows share one pass over the weights. A row's arithmetic
+// (k order, MFMA sequence, reduction order) is the same for RH = 1 and RH = 2 and for any number of live rows.
+// Fragment-ordered activations of more than 16 rows are two 16-row images one after the other (common.h xf_off_rows).
+
 // Row scales of the folded RMSNorm (GemvArgs::ssq_in). The n_part per-tile partials of every row are summed in a fixed
 // order that does not depend on the batch: lane (g, b) of scale wave w (the first SW = min(WAVES, 4) waves) owns the
 // contiguous slice [(g * SW + w) * per, + per) of row b, per = n_part / (4 * SW) <= 16. The loads are the FIRST loads a wave
 // issues (oldest in its in-order queue) and nothing reads them until the wave has finished its first unit, so they cost no
-// stall; the slice sums meet in LDS (sh_ps[w][lane]) and the epilogue wave adds them w-major, g-minor.
-struct ScaleRegs { f32x4 v[4]; };
-template <int SW>
-__device__ __forceinline__ void scale_load(const GemvArgs& a, ScaleRegs& r, int w, int lane) {
+// stall; the slice sums meet in LDS (sh_ps[w][half][lane]) and the epilogue wave adds them w-major, g-minor.
+template <int RH> struct ScaleRegs { f32x4 v[RH][4]; };
+template <int SW, int RH>
+__device__ __forceinline__ void scale_load(const GemvArgs& a, ScaleRegs<RH>& r, int w, int lane) {
+  const int g = lane >> 4;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) r.v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int g = lane >> 4, b = lane & 15;
-  if (!a.ssq_in || w >= SW || b >= a.M) return;
-  const int per = a.n_part / (4 * SW);
-  const float* p = a.ssq_in + (size_t)b * a.n_part + (g * SW + w) * per;
-  if ((per & 3) == 0) {
+  for (int hf = 0; hf < RH; ++hf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (4 * i < per) r.v[i] = *(const f32x4*)(p + 4 * i);
-  } else {   // narrow models (n_part < 16 * SW): per is 1 or 2
-    r.v[0][0] = p[0];
-    if (per > 1) r.v[0][1] = p[1];
+    for (int i = 0; i < 4; ++i) r.v[hf][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int b = (lane & 15) + 16 * hf;
+    if (!a.ssq_in || w >= SW || b >= a.M) continue;
+    const int per = a.n_part / (4 * SW);
+    const float* p = a.ssq_in + (size_t)b * a.n_part + (g * SW + w) * per;
+    if ((per & 3) == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (4 * i < per) r.v[hf][i] = *(const f32x4*)(p + 4 * i);
+    } else {   // narrow models (n_part < 16 * SW): per is 1 or 2
+      r.v[hf][0][0] = p[0];
+      if (per > 1) r.v[hf][0][1] = p[1];
+    }
   }
 }
-template <int SW>
-__device__ __forceinline__ void scale_park(const GemvArgs& a, const ScaleRegs& r, float (*sh_ps)[64], int w, int lane) {
+template <int SW, int RH>
+__device__ __forceinline__ void scale_park(const GemvArgs& a, const ScaleRegs<RH>& r, float (*sh_ps)[RH][64], int w, int lane) {
   if (!a.ssq_in || w >= SW) return;
-  float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { s += r.v[i][0]; s += r.v[i][1]; s += r.v[i][2]; s += r.v[i][3]; }
-  sh_ps[w][lane] = s;
+  for (int hf = 0; hf < RH; ++hf) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s += r.v[hf][i][0]; s += r.v[hf][i][1]; s += r.v[hf][i][2]; s += r.v[hf][i][3]; }
+    sh_ps[w][hf][lane] = s;
+  }
 }
-template <int SW>
-__device__ __forceinline__ float scale_of_row(const GemvArgs& a, const float (*sh_ps)[64], int b) {
+template <int SW, int RH>
+__device__ __forceinline__ float scale_of_row(const GemvArgs& a, const float (*sh_ps)[RH][64], int hf, int b16) {
   float s = 0.f;
 #pragma unroll
   for (int w = 0; w < SW; ++w)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) s += sh_ps[w][g * 16 + b];
+    for (int g = 0; g < 4; ++g) s += sh_ps[w][hf][g * 16 + b16];
   return rsqrtf(s / (float)a.norm_d + a.norm_eps);
 }
 
-// ---- epilogues. `red` = this unit's partial D tiles [WAVES][NT][64 lanes][4]; a lane holds column b = lane & 15 (batch
-// row) and rows n = 16 * tile + 4 * (lane >> 4) + r of a D tile.
+// ---- epilogues. `red` = this unit's partial D tiles [WAVES][NT][RH][64 lanes][4]; a lane holds column b = lane & 15 (+ 16 per
+// row half) and rows n = 16 * tile + 4 * (lane >> 4) + r of a D tile.
 // Paired epilogues (one wave): tile 0 and tile 1 of the unit are partners (gate / up, or rotary halves).
-template <int NT, int EPI, int WAVES>
-__device__ __forceinline__ void epilogue_pair(const GemvArgs& a, const float (*red)[NT][64][4], int pair, int lane,
-                                              const float (*sh_ps)[64]) {
+template <int NT, int EPI, int WAVES, int RH>
+__device__ __forceinline__ void epilogue_pair(const GemvArgs& a, const float (*red)[NT][RH][64][4], int pair, int lane,
+                                              const float (*sh_ps)[RH][64]) {
   static_assert(NT == 2, "paired tiles");
-  const int g = lane >> 4, b = lane & 15;
-  f32x4 t0 = f32x4{0.f, 0.f, 0.f, 0.f}, t1 = t0;
+  constexpr int SW = WAVES < 4 ? WAVES : 4;
+  const int g = lane >> 4;
 #pragma unroll
-  for (int i = 0; i < WAVES; ++i) {
-    t0 += *(const f32x4*)&red[i][0][lane][0];
-    t1 += *(const f32x4*)&red[i][1][lane][0];
-  }
-  if (b >= a.M) return;
-  if (a.ssq_in) {   // folded RMSNorm: the row's scale, applied before the first rounding
-    const float rs = scale_of_row<(WAVES < 4 ? WAVES : 4)>(a, sh_ps, b);
-    t0 *= rs;
-    t1 *= rs;
-  }
-  if constexpr (EPI == EPI_SWIGLU) {
-    const int n = pair * 16 + 4 * g;
-    if (n >= a.Nvalid) return;
-    float o[4];
+  for (int hf = 0; hf < RH; ++hf) {
+    const int b = (lane & 15) + 16 * hf;
+    f32x4 t0 = f32x4{0.f, 0.f, 0.f, 0.f}, t1 = t0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float gg = rbf(t0[r]);
-      const float s = rbf(gg * sigmoidf_(gg));
-      o[r] = s * rbf(t1[r]);
+    for (int i = 0; i < WAVES; ++i) {
+      t0 += *(const f32x4*)&red[i][0][hf][lane][0];
+      t1 += *(const f32x4*)&red[i][1][hf][lane][0];
     }
-    u32x2 st = {pack2(o[0], o[1]), pack2(o[2], o[3])};
-    *(u32x2*)((bf16_t*)a.C + (a.c_xf ? xf_off(b, n) : (size_t)b * a.ldc + n)) = st;
-  } else {
-    // rows were packed so that tile 0 holds head dims [d0, d0+16) and tile 1 their rotary partners [d0+64, ...)
-    const int hs = pair >> 2, d = (pair & 3) * 16 + 4 * g;
-    const int sec = hs / a.H, h = hs % a.H;
-    const int sl = a.map.slot[b];
-    if (sl < 0) return;                                              // inactive decode row
-    const int len = a.cur_len[sl];
-    const int pos_raw = len - 1 - a.kbeg[sl];
-    const int pos = pos_raw < 0 ? 0 : (pos_raw >= a.maxpos ? a.maxpos - 1 : pos_raw);
-    const int slot = len - 1;
-    float lo[4], hi[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { lo[r] = rbf(t0[r]); hi[r] = rbf(t1[r]); }
-    if (sec < 2) {
-      const u32x2 cv = *(const u32x2*)(a.cos_tab + (size_t)pos * 64 + d);
-      const u32x2 sv = *(const u32x2*)(a.sin_tab + (size_t)pos * 64 + d);
-      const float c[4] = {lo_bf(cv[0]), hi_bf(cv[0]), lo_bf(cv[1]), hi_bf(cv[1])};
-      const float s[4] = {lo_bf(sv[0]), hi_bf(sv[0]), lo_bf(sv[1]), hi_bf(sv[1])};
-      float ol[4], oh[4];
+    if (b >= a.M) continue;
+    if (a.ssq_in) {   // folded RMSNorm: the row's scale, applied before the first rounding
+      const float rs = scale_of_row<SW, RH>(a, sh_ps, hf, lane & 15);
+      t0 *= rs;
+      t1 *= rs;
+    }
+    if constexpr (EPI == EPI_SWIGLU) {
+      const int n = pair * 16 + 4 * g;
+      if (n >= a.Nvalid) continue;
+      float o[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        ol[r] = rbf(lo[r] * c[r]) + rbf(-hi[r] * s[r]);
-        oh[r] = rbf(hi[r] * c[r]) + rbf(lo[r] * s[r]);
+        const float gg = rbf(t0[r]);
+        const float s = rbf(gg * sigmoidf_(gg));
+        o[r] = s * rbf(t1[r]);
       }
+      u32x2 st = {pack2(o[0], o[1]), pack2(o[2], o[3])};
+      *(u32x2*)((bf16_t*)a.C + (a.c_xf ? xf_off_rows(b, n, a.ldc) : (size_t)b * a.ldc + n)) = st;
+    } else {
+      // rows were packed so that tile 0 holds head dims [d0, d0+16) and tile 1 their rotary partners [d0+64, ...)
+      const int hs = pair >> 2, d = (pair & 3) * 16 + 4 * g;
+      const int sec = hs / a.H, h = hs % a.H;
+      const int sl = a.map.slot[b];
+      if (sl < 0) continue;                                            // inactive decode row
+      const int len = a.cur_len[sl];
+      const int pos_raw = len - 1 - a.kbeg[sl];
+      const int pos = pos_raw < 0 ? 0 : (pos_raw >= a.maxpos ? a.maxpos - 1 : pos_raw);
+      const int slot = len - 1;
+      float lo[4], hi[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { lo[r] = ol[r]; hi[r] = oh[r]; }
+      for (int r = 0; r < 4; ++r) { lo[r] = rbf(t0[r]); hi[r] = rbf(t1[r]); }
+      if (sec < 2) {
+        const u32x2 cv = *(const u32x2*)(a.cos_tab + (size_t)pos * 64 + d);
+        const u32x2 sv = *(const u32x2*)(a.sin_tab + (size_t)pos * 64 + d);
+        const float c[4] = {lo_bf(cv[0]), hi_bf(cv[0]), lo_bf(cv[1]), hi_bf(cv[1])};
+        const float s[4] = {lo_bf(sv[0]), hi_bf(sv[0]), lo_bf(sv[1]), hi_bf(sv[1])};
+        float ol[4], oh[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          ol[r] = rbf(lo[r] * c[r]) + rbf(-hi[r] * s[r]);
+          oh[r] = rbf(hi[r] * c[r]) + rbf(lo[r] * s[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { lo[r] = ol[r]; hi[r] = oh[r]; }
+      }
+      bf16_t* dst;
+      if (sec == 0)
+        dst = (bf16_t*)a.C + (size_t)b * a.ldc + h * 128 + d;
+      else
+        dst = (sec == 1 ? a.Kc : a.Vc) + (size_t)sl * a.c_bs + (size_t)h * a.c_hs + (size_t)slot * 128 + d;
+      u32x2 s0 = {pack2(lo[0], lo[1]), pack2(lo[2], lo[3])};
+      u32x2 s1 = {pack2(hi[0], hi[1]), pack2(hi[2], hi[3])};
+      *(u32x2*)dst = s0;
+      *(u32x2*)(dst + 64) = s1;
     }
-    bf16_t* dst;
-    if (sec == 0)
-      dst = (bf16_t*)a.C + (size_t)b * a.ldc + h * 128 + d;
-    else
-      dst = (sec == 1 ? a.Kc : a.Vc) + (size_t)sl * a.c_bs + (size_t)h * a.c_hs + (size_t)slot * 128 + d;
-    u32x2 s0 = {pack2(lo[0], lo[1]), pack2(lo[2], lo[3])};
-    u32x2 s1 = {pack2(hi[0], hi[1]), pack2(hi[2], hi[3])};
-    *(u32x2*)dst = s0;
-    *(u32x2*)(dst + 64) = s1;
   }
 }
 
 // Un-paired epilogues: tile `nt` of the unit (global n-tile index `ntile`), one wave.
-template <int NT, int EPI, int WAVES>
-__device__ __forceinline__ void epilogue_tile(const GemvArgs& a, const float (*red)[NT][64][4], int nt, int ntile, int lane,
-                                              const float (*sh_ps)[64]) {
-  const int g = lane >> 4, b = lane & 15;
-  f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+template <int NT, int EPI, int WAVES, int RH>
+__device__ __forceinline__ void epilogue_tile(const GemvArgs& a, const float (*red)[NT][RH][64][4], int nt, int ntile, int lane,
+                                              const float (*sh_ps)[RH][64]) {
+  constexpr int SW = WAVES < 4 ? WAVES : 4;
+  const int g = lane >> 4;
 #pragma unroll
-  for (int i = 0; i < WAVES; ++i) v += *(const f32x4*)&red[i][nt][lane][0];
-  if (a.ssq_in) v *= scale_of_row<(WAVES < 4 ? WAVES : 4)>(a, sh_ps, b);   // folded RMSNorm (rows b >= M: sum 0, finite scale)
-  const int n = ntile * 16 + 4 * g;
-  const bool live = b < a.M && n < a.Nvalid;
-  float y[4];
-  float bb[4] = {0.f, 0.f, 0.f, 0.f};
-  if (a.bias && live) {
-    const u32x2 bv = *(const u32x2*)(a.bias + n);
-    bb[0] = lo_bf(bv[0]); bb[1] = hi_bf(bv[0]); bb[2] = lo_bf(bv[1]); bb[3] = hi_bf(bv[1]);
-  }
+  for (int hf = 0; hf < RH; ++hf) {
+    const int b = (lane & 15) + 16 * hf;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int r = 0; r < 4; ++r) y[r] = rbf(v[r] + bb[r]);
-  if constexpr (EPI == EPI_RESIDUAL) {
-    if (live) {
-      const u32x2 rv = *(const u32x2*)(a.R + (size_t)b * a.ldr + n);
-      y[0] += lo_bf(rv[0]); y[1] += hi_bf(rv[0]); y[2] += lo_bf(rv[1]); y[3] += hi_bf(rv[1]);
+    for (int i = 0; i < WAVES; ++i) v += *(const f32x4*)&red[i][nt][hf][lane][0];
+    if (a.ssq_in) v *= scale_of_row<SW, RH>(a, sh_ps, hf, lane & 15);   // folded RMSNorm (rows b >= M: sum 0, finite scale)
+    const int n = ntile * 16 + 4 * g;
+    const bool live = b < a.M && n < a.Nvalid;
+    float y[4];
+    float bb[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias && live) {
+      const u32x2 bv = *(const u32x2*)(a.bias + n);
+      bb[0] = lo_bf(bv[0]); bb[1] = hi_bf(bv[0]); bb[2] = lo_bf(bv[1]); bb[3] = hi_bf(bv[1]);
     }
-    if (a.ssq_out) {   // sum of squares of the stored (bf16) values of this n-tile, per batch row
-      float s = 0.f;
-      if (live) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const float t = rbf(y[r]); s += t * t; }
-      }
-      s += __shfl_xor(s, 16, 64);
-      s += __shfl_xor(s, 32, 64);
-      if (g == 0) a.ssq_out[b * (a.N >> 4) + ntile] = s;
-    }
-  } else if constexpr (EPI == EPI_GELU) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) y[r] = 0.5f * y[r] * (1.0f + erff(y[r] * 0.70710678118654752440f));
-  }
-  if (!live) return;
-  if constexpr (EPI == EPI_F32) {
-    *(f32x4*)((float*)a.C + (size_t)b * a.ldc + n) = f32x4{y[0], y[1], y[2], y[3]};
-  } else {
-    u32x2 st = {pack2(y[0], y[1]), pack2(y[2], y[3])};
-    *(u32x2*)((bf16_t*)a.C + (size_t)b * a.ldc + n) = st;
+    for (int r = 0; r < 4; ++r) y[r] = rbf(v[r] + bb[r]);
     if constexpr (EPI == EPI_RESIDUAL) {
-      if (a.C_xf) *(u32x2*)(a.C_xf + xf_off(b, n)) = st;
+      if (live) {
+        const u32x2 rv = *(const u32x2*)(a.R + (size_t)b * a.ldr + n);
+        y[0] += lo_bf(rv[0]); y[1] += hi_bf(rv[0]); y[2] += lo_bf(rv[1]); y[3] += hi_bf(rv[1]);
+      }
+      if (a.ssq_out) {   // sum of squares of the stored (bf16) values of this n-tile, per batch row
+        float s = 0.f;
+        if (live) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float t = rbf(y[r]); s += t * t; }
+        }
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if (g == 0 && b < a.M) a.ssq_out[b * (a.N >> 4) + ntile] = s;
+      }
+    } else if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) y[r] = 0.5f * y[r] * (1.0f + erff(y[r] * 0.70710678118654752440f));
+    }
+    if (!live) continue;
+    if constexpr (EPI == EPI_F32) {
+      *(f32x4*)((float*)a.C + (size_t)b * a.ldc + n) = f32x4{y[0], y[1], y[2], y[3]};
+    } else {
+      u32x2 st = {pack2(y[0], y[1]), pack2(y[2], y[3])};
+      *(u32x2*)((bf16_t*)a.C + (size_t)b * a.ldc + n) = st;
+      if constexpr (EPI == EPI_RESIDUAL) {
+        if (a.C_xf) *(u32x2*)(a.C_xf + xf_off_rows(b, n, a.ldc)) = st;
+      }
     }
   }
 }
 
-template <int NT, int EPI, int WAVES, int U, int KMODE>
-__global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs a) {
-  __shared__ __attribute__((aligned(16))) float red[WAVES][NT][64][4];
-  constexpr int SW = WAVES < 4 ? WAVES : 4;
-  __shared__ float sh_ps[SW][64];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+// this lane's activation fragment pointers (one per row half) and the k-tile stride
+template <int RH>
+__device__ __forceinline__ void x_pointers(const GemvArgs& a, int lane, const bf16_t* (&xp)[RH], bool (&row_ok)[RH], int& xstep) {
   const int g = lane >> 4, r16 = lane & 15;
+#pragma unroll
+  for (int hf = 0; hf < RH; ++hf) {
+    const int row = r16 + 16 * hf;
+    row_ok[hf] = row < a.M;
+    const int rr = row_ok[hf] ? row : 0;
+    xp[hf] = a.x_xf ? a.X + (size_t)(rr >> 4) * 16 * a.K + (g * 16 + (rr & 15)) * 8 : a.X + (size_t)rr * a.ldx + g * 8;
+  }
+  xstep = a.x_xf ? 512 : 32;   // elements between this lane's fragments of consecutive k-tiles
+}
+
+template <int NT, int EPI, int WAVES, int U, int KMODE, int RH>
+__global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[WAVES][NT][RH][64][4];
+  constexpr int SW = WAVES < 4 ? WAVES : 4;
+  __shared__ float sh_ps[SW][RH][64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int KT = a.K >> 5;
   const int ntile0 = blockIdx.x * NT;
-  ScaleRegs sc;
-  scale_load<SW>(a, sc, w, lane);
+  ScaleRegs<RH> sc;
+  scale_load<SW, RH>(a, sc, w, lane);
   // this wave's k-tiles: kt(i) = k0 + i * kstep, i < nk
   int k0, kstep, nk;
   if constexpr (KMODE == 0) {
@@ -206,23 +241,23 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs a) {
     k0 = w; kstep = WAVES;
     nk = (KT - w + WAVES - 1) / WAVES; nk = nk < 0 ? 0 : nk;
   }
-  const bool row_ok = r16 < a.M;
-
-  const bf16_t* xp = a.x_xf ? a.X + (g * 16 + (row_ok ? r16 : 0)) * 8 : a.X + (size_t)(row_ok ? r16 : 0) * a.ldx + g * 8;
-  const int xstep = a.x_xf ? 512 : 32;                              // elements between this lane's fragments of consecutive k-tiles
+  const bf16_t* xp[RH];
+  bool row_ok[RH];
+  int xstep;
+  x_pointers<RH>(a, lane, xp, row_ok, xstep);
   const bf16_t* wp[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) wp[nt] = a.Wp + (size_t)(ntile0 + nt) * KT * 512 + lane * 8;
 
   bf16x8 wA[U][NT], wB[U][NT];
-  u32x4 xA[U], xB[U];
+  u32x4 xA[U][RH], xB[U][RH];
   // defined contents for the slots a short k-run never loads (their MFMAs are skipped by the same uniform branch;
   // leaving them undefined lets the compiler poison the accumulator)
 #pragma unroll
   for (int u = 0; u < U; ++u)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) wA[u][nt] = wB[u][nt] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-  auto wload = [&](bf16x8 (&dst)[U][NT], u32x4 (&xd)[U], int i) {
+  auto wload = [&](bf16x8 (&dst)[U][NT], u32x4 (&xd)[U][RH], int i) {
 #pragma unroll
     for (int u = 0; u < U; ++u)
       if (i + u < nk) {   // wave-uniform: a real branch, the loads stay un-waited until their MFMA
@@ -231,25 +266,32 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs a) {
         for (int nt = 0; nt < NT; ++nt) dst[u][nt] = __builtin_nontemporal_load((const bf16x8*)(wp[nt] + (size_t)kt * 512));
       }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      xd[u] = u32x4{0u, 0u, 0u, 0u};
-      if (i + u < nk && row_ok) xd[u] = *(const u32x4*)(xp + (size_t)(k0 + (i + u) * kstep) * xstep);
-    }
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int hf = 0; hf < RH; ++hf) {
+        xd[u][hf] = u32x4{0u, 0u, 0u, 0u};
+        if (i + u < nk && row_ok[hf]) xd[u][hf] = *(const u32x4*)(xp[hf] + (size_t)(k0 + (i + u) * kstep) * xstep);
+      }
   };
   wload(wA, xA, 0);
   wload(wB, xB, U);
 
-  f32x4 acc[NT];
+  f32x4 acc[NT][RH];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int hf = 0; hf < RH; ++hf) acc[nt][hf] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  auto compute = [&](bf16x8 (&src)[U][NT], u32x4 (&xs)[U], int i) {
+  auto compute = [&](bf16x8 (&src)[U][NT], u32x4 (&xs)[U][RH], int i) {
 #pragma unroll
     for (int u = 0; u < U; ++u)
       if (i + u < nk) {
-        const bf16x8 xf = __builtin_bit_cast(bf16x8, xs[u]);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(src[u][nt], xf, acc[nt], 0, 0, 0);
+        for (int hf = 0; hf < RH; ++hf) {
+          const bf16x8 xf = __builtin_bit_cast(bf16x8, xs[u][hf]);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[nt][hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(src[u][nt], xf, acc[nt][hf], 0, 0, 0);
+        }
       }
   };
 
@@ -261,14 +303,16 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs a) {
   }
 
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) *(f32x4*)&red[w][nt][lane][0] = acc[nt];
-  scale_park<SW>(a, sc, sh_ps, w, lane);
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int hf = 0; hf < RH; ++hf) *(f32x4*)&red[w][nt][hf][lane][0] = acc[nt][hf];
+  scale_park<SW, RH>(a, sc, sh_ps, w, lane);
   __syncthreads();
 
   if constexpr (EPI == EPI_SWIGLU || EPI == EPI_ROPE_KV) {
-    if (w == 0) epilogue_pair<NT, EPI, WAVES>(a, red, blockIdx.x, lane, sh_ps);
+    if (w == 0) epilogue_pair<NT, EPI, WAVES, RH>(a, red, blockIdx.x, lane, sh_ps);
   } else {
-    if (w < NT) epilogue_tile<NT, EPI, WAVES>(a, red, w, ntile0 + w, lane, sh_ps);
+    if (w < NT) epilogue_tile<NT, EPI, WAVES, RH>(a, red, w, ntile0 + w, lane, sh_ps);
   }
 }
 
@@ -278,29 +322,29 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs a) {
 // At a unit boundary each wave parks its partial tiles in LDS (two parities), one barrier, and ONE wave (rotating)
 // runs the epilogue while the others are already multiplying the next unit. Bytes in flight per CU are set by
 // WAVES * 2 * U * NT KiB and not by how many workgroups happen to share the CU.
-template <int NT, int EPI, int WAVES, int U>
+template <int NT, int EPI, int WAVES, int U, int RH>
 __global__ __launch_bounds__(WAVES * 64) void gemv_pers_kernel(GemvArgs a, int units) {
-  __shared__ __attribute__((aligned(16))) float red[2][WAVES][NT][64][4];
+  __shared__ __attribute__((aligned(16))) float red[2][WAVES][NT][RH][64][4];
   constexpr int SW = WAVES < 4 ? WAVES : 4;
-  __shared__ float sh_ps[SW][64];
+  __shared__ float sh_ps[SW][RH][64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  ScaleRegs sc;
-  scale_load<SW>(a, sc, w, lane);
-  const int g = lane >> 4, r16 = lane & 15;
+  ScaleRegs<RH> sc;
+  scale_load<SW, RH>(a, sc, w, lane);
   const int KT = a.K >> 5;
   const int nk = (KT - w + WAVES - 1) / WAVES;                       // >= 1 (host: KT >= WAVES)
   const int G = gridDim.x;
   const int nu = (units - (int)blockIdx.x + G - 1) / G;             // >= 1 (host: G <= units)
   const int T = nu * nk;                                            // steps of this wave's stream
-  const bool row_ok = r16 < a.M;
-  const bf16_t* xp = a.x_xf ? a.X + (g * 16 + (row_ok ? r16 : 0)) * 8 : a.X + (size_t)(row_ok ? r16 : 0) * a.ldx + g * 8;
-  const int xstep = a.x_xf ? 512 : 32;                              // elements between this lane's fragments of consecutive k-tiles
+  const bf16_t* xp[RH];
+  bool row_ok[RH];
+  int xstep;
+  x_pointers<RH>(a, lane, xp, row_ok, xstep);
   const size_t unit_stride = (size_t)NT * KT * 512;                 // elements between consecutive units
   const bf16_t* wbase = a.Wp + (size_t)blockIdx.x * unit_stride + lane * 8;
 
   bf16x8 wA[U][NT], wB[U][NT];
-  u32x4 xA[U], xB[U];
+  u32x4 xA[U][RH], xB[U][RH];
 #pragma unroll
   for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -309,16 +353,19 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_pers_kernel(GemvArgs a, int u
   // load cursor: step ls = (unit lj, k index li)
   int ls = 0, li = 0;
   const bf16_t* lw = wbase;                                         // weights of the load cursor's unit
-  auto wload = [&](bf16x8 (&dst)[U][NT], u32x4 (&xd)[U]) {
+  auto wload = [&](bf16x8 (&dst)[U][NT], u32x4 (&xd)[U][RH]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      xd[u] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int hf = 0; hf < RH; ++hf) xd[u][hf] = u32x4{0u, 0u, 0u, 0u};
       if (ls < T) {                                                  // wave-uniform
         const int kt = w + li * WAVES;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
           dst[u][nt] = __builtin_nontemporal_load((const bf16x8*)(lw + ((size_t)nt * KT + kt) * 512));
-        if (row_ok) xd[u] = *(const u32x4*)(xp + (size_t)kt * xstep);
+#pragma unroll
+        for (int hf = 0; hf < RH; ++hf)
+          if (row_ok[hf]) xd[u][hf] = *(const u32x4*)(xp[hf] + (size_t)kt * xstep);
         ++ls;
         if (++li == nk) { li = 0; lw += (size_t)G * unit_stride; }
       }
@@ -327,35 +374,42 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_pers_kernel(GemvArgs a, int u
   wload(wA, xA);
   wload(wB, xB);
 
-  f32x4 acc[NT];
+  f32x4 acc[NT][RH];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int hf = 0; hf < RH; ++hf) acc[nt][hf] = f32x4{0.f, 0.f, 0.f, 0.f};
   int cs = 0, ci = 0, cj = 0;                                       // compute cursor
-  auto compute = [&](bf16x8 (&src)[U][NT], u32x4 (&xs)[U]) {
+  auto compute = [&](bf16x8 (&src)[U][NT], u32x4 (&xs)[U][RH]) {
 #pragma unroll
     for (int u = 0; u < U; ++u)
       if (cs < T) {
-        const bf16x8 xf = __builtin_bit_cast(bf16x8, xs[u]);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(src[u][nt], xf, acc[nt], 0, 0, 0);
+        for (int hf = 0; hf < RH; ++hf) {
+          const bf16x8 xf = __builtin_bit_cast(bf16x8, xs[u][hf]);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[nt][hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(src[u][nt], xf, acc[nt][hf], 0, 0, 0);
+        }
         ++cs;
         if (++ci == nk) {                                            // unit cj complete: every wave passes here nu times
           ci = 0;
-          float (*rp)[NT][64][4] = red[cj & 1];
+          float (*rp)[NT][RH][64][4] = red[cj & 1];
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            *(f32x4*)&rp[w][nt][lane][0] = acc[nt];
-            acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-          }
-          if (cj == 0) scale_park<SW>(a, sc, sh_ps, w, lane);      // once, before the first epilogue of the workgroup
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int hf = 0; hf < RH; ++hf) {
+              *(f32x4*)&rp[w][nt][hf][lane][0] = acc[nt][hf];
+              acc[nt][hf] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+          if (cj == 0) scale_park<SW, RH>(a, sc, sh_ps, w, lane);  // once, before the first epilogue of the workgroup
           __syncthreads();
           if (w == cj % WAVES) {
             const int unit = blockIdx.x + cj * G;
             if constexpr (EPI == EPI_SWIGLU || EPI == EPI_ROPE_KV) {
-              epilogue_pair<NT, EPI, WAVES>(a, rp, unit, lane, sh_ps);
+              epilogue_pair<NT, EPI, WAVES, RH>(a, rp, unit, lane, sh_ps);
             } else {
 #pragma unroll
-              for (int nt = 0; nt < NT; ++nt) epilogue_tile<NT, EPI, WAVES>(a, rp, nt, unit * NT + nt, lane, sh_ps);
+              for (int nt = 0; nt < NT; ++nt) epilogue_tile<NT, EPI, WAVES, RH>(a, rp, nt, unit * NT + nt, lane, sh_ps);
             }
           }
           ++cj;
@@ -370,22 +424,33 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_pers_kernel(GemvArgs a, int u
   }
 }
 
-template <int NT, int EPI, int WAVES, int U>
-void go_pers(const GemvArgs& a, int ntiles, int grid, hipStream_t s) {
+template <int NT, int EPI, int WAVES, int U, int RH>
+void go_pers_rh(const GemvArgs& a, int ntiles, int grid, hipStream_t s) {
   if (a.ev_start)
-    hipExtLaunchKernelGGL((gemv_pers_kernel<NT, EPI, WAVES, U>), dim3(grid), dim3(WAVES * 64), 0, s, (hipEvent_t)a.ev_start,
+    hipExtLaunchKernelGGL((gemv_pers_kernel<NT, EPI, WAVES, U, RH>), dim3(grid), dim3(WAVES * 64), 0, s, (hipEvent_t)a.ev_start,
                           (hipEvent_t)a.ev_stop, 0, a, ntiles / NT);
   else
-    hipLaunchKernelGGL((gemv_pers_kernel<NT, EPI, WAVES, U>), dim3(grid), dim3(WAVES * 64), 0, s, a, ntiles / NT);
+    hipLaunchKernelGGL((gemv_pers_kernel<NT, EPI, WAVES, U, RH>), dim3(grid), dim3(WAVES * 64), 0, s, a, ntiles / NT);
+}
+// more than 16 rows: the two-row-half kernels (same weights pass, two B fragments per weight fragment)
+template <int NT, int EPI, int WAVES, int U>
+void go_pers(const GemvArgs& a, int ntiles, int grid, hipStream_t s) {
+  if (a.M > 16) go_pers_rh<NT, EPI, WAVES, U, 2>(a, ntiles, grid, s);
+  else go_pers_rh<NT, EPI, WAVES, U, 1>(a, ntiles, grid, s);
 }
 
-template <int NT, int EPI, int WAVES, int U, int KMODE>
-void go(const GemvArgs& a, int ntiles, hipStream_t s) {
+template <int NT, int EPI, int WAVES, int U, int KMODE, int RH>
+void go_rh(const GemvArgs& a, int ntiles, hipStream_t s) {
   if (a.ev_start)
-    hipExtLaunchKernelGGL((gemv_kernel<NT, EPI, WAVES, U, KMODE>), dim3(ntiles / NT), dim3(WAVES * 64), 0, s, (hipEvent_t)a.ev_start,
+    hipExtLaunchKernelGGL((gemv_kernel<NT, EPI, WAVES, U, KMODE, RH>), dim3(ntiles / NT), dim3(WAVES * 64), 0, s, (hipEvent_t)a.ev_start,
                           (hipEvent_t)a.ev_stop, 0, a);
   else
-    hipLaunchKernelGGL((gemv_kernel<NT, EPI, WAVES, U, KMODE>), dim3(ntiles / NT), dim3(WAVES * 64), 0, s, a);
+    hipLaunchKernelGGL((gemv_kernel<NT, EPI, WAVES, U, KMODE, RH>), dim3(ntiles / NT), dim3(WAVES * 64), 0, s, a);
+}
+template <int NT, int EPI, int WAVES, int U, int KMODE>
+void go(const GemvArgs& a, int ntiles, hipStream_t s) {
+  if (a.M > 16) go_rh<NT, EPI, WAVES, U, KMODE, 2>(a, ntiles, s);
+  else go_rh<NT, EPI, WAVES, U, KMODE, 1>(a, ntiles, s);
 }
 
 // Tuned on MI355X with tools/decode_bench (M = 8, LLaMA-7B shapes). Shallow load queues win everywhere (deeper unrolls
@@ -449,7 +514,7 @@ hipError_t pick(const GemvArgs& a, int ntiles, int variant, hipStream_t s) {
 // variant 0 = tuned default; others (GEMV_ALL_VARIANTS builds only) select (WAVES, U, KMODE) for tools/decode_bench
 hipError_t launch_gemv_ex(const GemvArgs& a, int epi, int variant, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
-  if (a.M > 16 || (a.K & 31) || (a.N & 15)) return hipErrorInvalidValue;
+  if (a.M > 32 || (a.K & 31) || (a.N & 15)) return hipErrorInvalidValue;
   const int ntiles = a.N / 16;
   switch (epi) {
     case EPI_NONE: return pick<1, EPI_NONE>(a, ntiles, variant, s);

@@ -12,7 +12,10 @@ int orc_fail(const char* what, const char* detail);
 // batch) uses the per-slot greedy state and the KV-cache rows of slot[b]; -1 = inactive row (nothing read or written).
 // The host changes the map between launches without touching device memory (continuous batching: a finished frame's
 // decode row is pointed at a slot that was prefilled ahead of time).
-struct RowMap { int slot[16] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}; };   // default: row b <-> slot b
+constexpr int kMaxRows = 32;    // rows of one decode / prefill launch (two MFMA B-operand tiles of 16 in the decode GEMVs)
+struct RowMap {                 // default: row b <-> slot b
+  int slot[kMaxRows] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31};
+};
 inline RowMap identity_map() { return RowMap(); }
 
 enum { EPI_NONE = 0, EPI_QUICKGELU = 1, EPI_GELU = 2, EPI_RESIDUAL = 3, EPI_SWIGLU = 4, EPI_F32 = 5, EPI_ROPE_KV = 6 };
@@ -104,7 +107,7 @@ struct DecodeAttnArgs {
   RowMap map;                                // row -> slot (kbeg / cur_len / unfinished / cache rows); Q, O and part are per row
   int B, H;
   float scale;
-  int o_xf;                                  // write O in the fragment-ordered layout (common.h xf_off), k = h * 128 + d
+  int o_xf;                                  // write O in the fragment-ordered layout (common.h xf_off, 16-row images), k = h * 128 + d
 };
 #define DECODE_NSPLIT 8   // capacity of the split-KV partial buffer; the launch picks 2..8 splits by batch
 hipError_t launch_decode_attention(const DecodeAttnArgs& a, hipStream_t s, int variant = 0);
@@ -138,7 +141,7 @@ hipError_t launch_gather_rows(const int* codes, const bf16_t* tok, const bf16_t*
                               int rows, int d, hipStream_t s);
 // out[r] = tok[id_r], id_r = ids_by_row[r] when given (teacher forcing), else ids_by_slot[map.slot[r]] (inactive row: token 0);
 // when ssq_part != null also part[r][0] = sum(out[r]^2), part[r][1..n_part) = 0; when out_xf != null the rows are also
-// written in the fragment-ordered layout (rows <= 16)
+// written in the fragment-ordered layout (rows <= 32: two 16-row images)
 hipError_t launch_embed_tokens(const int* ids_by_row, const int* ids_by_slot, const RowMap& map, const bf16_t* tok, bf16_t* out,
                                int rows, int d, int vocab, float* ssq_part, int n_part, hipStream_t s, bf16_t* out_xf = nullptr);
 hipError_t launch_view_reduce(const bf16_t* x, bf16_t* out, int B, int V, int n, int mode, hipStream_t s);
@@ -173,11 +176,11 @@ hipError_t launch_argmax_sample(const SampleArgs& a, hipStream_t s);
 // ---- per-slot greedy state (re)initialisation for a prefill: one block per prefilled row, everything by value
 struct SlotInitArgs {
   RowMap map; int k;                 // prefill row i -> slot
-  int kbeg[16]; int limit[16];       // per prefill row: left pad, length stop
+  int kbeg[kMaxRows]; int limit[kMaxRows];   // per prefill row: left pad, length stop
   int T; int pad_id; int out_ld;
   int *unfinished, *kbeg_state, *cur_len, *row_step, *limit_state, *tokens;   // per-slot state arrays
-  int* pf_kbeg;                      // [16] per prefill ROW copy of kbeg (read by the prefill attention)
+  int* pf_kbeg;                      // [kMaxRows] per prefill ROW copy of kbeg (read by the prefill attention)
 };
 hipError_t launch_slot_init(const SlotInitArgs& a, hipStream_t s);
-struct ScatterArgs { RowMap map; int n; int val[16]; int* dst; };   // dst[map.slot[i]] = val[i]
+struct ScatterArgs { RowMap map; int n; int val[kMaxRows]; int* dst; };   // dst[map.slot[i]] = val[i]
 hipError_t launch_scatter_ints(const ScatterArgs& a, hipStream_t s);

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(128) void embed_tokens_kernel(const int* __restrict
   for (int c = threadIdx.x; c < (d >> 3); c += 128) {
     const u32x4 v = *(const u32x4*)(tok + (size_t)id * d + c * 8);
     *(u32x4*)(out + (size_t)row * d + c * 8) = v;
-    if (out_xf) *(u32x4*)(out_xf + xf_off(row, c * 8)) = v;
+    if (out_xf) *(u32x4*)(out_xf + xf_off_rows(row, c * 8, d)) = v;
 #pragma unroll
     for (int j = 0; j < 4; ++j) ss += lo_bf(v[j]) * lo_bf(v[j]) + hi_bf(v[j]) * hi_bf(v[j]);
   }
@@ -398,7 +398,7 @@ hipError_t launch_gather_rows(const int* codes, const bf16_t* tok, const bf16_t*
 hipError_t launch_embed_tokens(const int* ids_by_row, const int* ids_by_slot, const RowMap& map, const bf16_t* tok, bf16_t* out,
                                int rows, int d, int vocab, float* ssq_part, int n_part, hipStream_t s, bf16_t* out_xf) {
   if (rows <= 0) return hipSuccess;
-  if (rows > 16) return hipErrorInvalidValue;
+  if (rows > kMaxRows) return hipErrorInvalidValue;
   hipLaunchKernelGGL(embed_tokens_kernel, dim3(rows), dim3(128), 0, s, ids_by_row, ids_by_slot, map, tok, out, d, vocab, ssq_part,
                      n_part, out_xf);
   return hipGetLastError();
@@ -421,17 +421,17 @@ hipError_t launch_preprocess(const uint8_t* img, int n, int H, int W, int out, c
   return hipGetLastError();
 }
 hipError_t launch_slot_init(const SlotInitArgs& a, hipStream_t s) {
-  if (a.k < 1 || a.k > 16) return hipErrorInvalidValue;
+  if (a.k < 1 || a.k > kMaxRows) return hipErrorInvalidValue;
   hipLaunchKernelGGL(slot_init_kernel, dim3(a.k), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 hipError_t launch_scatter_ints(const ScatterArgs& a, hipStream_t s) {
-  if (a.n < 1 || a.n > 16) return hipErrorInvalidValue;
+  if (a.n < 1 || a.n > kMaxRows) return hipErrorInvalidValue;
   hipLaunchKernelGGL(scatter_ints_kernel, dim3(1), dim3(64), 0, s, a);
   return hipGetLastError();
 }
 hipError_t launch_argmax_sample(const SampleArgs& a, hipStream_t s) {
-  if ((a.vocab & 3) || a.B <= 0 || a.B > 16 || a.n_count > 16) return hipErrorInvalidValue;
+  if ((a.vocab & 3) || a.B <= 0 || a.B > kMaxRows || a.n_count > kMaxRows) return hipErrorInvalidValue;
   hipLaunchKernelGGL(argmax_sample_kernel, dim3(a.B), dim3(1024), 0, s, a);
   hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, s, a);
   return hipGetLastError();

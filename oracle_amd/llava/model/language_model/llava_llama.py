@@ -214,7 +214,7 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
         """generate() over a stream of batches with continuous batching. The reference decodes batch
         after batch (scene_graph_prediction_model_oracle.py:251-260) and every batch runs as long as its longest answer;
         frames are independent, so here a decode row whose frame has finished (EOS / length stop) continues with the next
-        frame. The engine has max_batch KV-cache slots and decodes n_rows rows (default: half the slots, at most 16): the
+        frame. The engine has max_batch KV-cache slots and decodes n_rows rows (default: half the slots, at most 32): the
         next incoming batch is prefilled AHEAD, as one left-padded batch (same kernels and shapes as generate()), into the
         free slots while the current frames decode, and a finished row is simply re-attached to a waiting slot. Vision,
         pooling, projection and the splice run per incoming batch, exactly as in generate().
@@ -230,8 +230,8 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
         if max_new_tokens > eng.max_new_tokens:
             raise ValueError(f'max_new_tokens {max_new_tokens} exceeds the engine capacity {eng.max_new_tokens}')
         n_slots = eng.max_batch
-        n_rows = max(1, min(16, n_slots // 2)) if n_rows is None else n_rows
-        if not 1 <= n_rows <= min(16, n_slots):
+        n_rows = max(1, min(32, n_slots // 2)) if n_rows is None else n_rows
+        if not 1 <= n_rows <= min(32, n_slots):
             raise ValueError(f'n_rows {n_rows} outside 1..{n_slots} (the engine\'s KV-cache slots)')
         pad, eos = self.config.pad_token_id, self.config.eos_token_id
         it = iter(batches)

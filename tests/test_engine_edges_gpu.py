@@ -144,3 +144,28 @@ def test_random_ragged_batches_match_oracle(chain16, seed):
         model.config.mv_type = 'learned'
     ref = cr.greedy_generate(st, TINY, ids, imgs, mv_type=mv, max_new_tokens=40)
     assert torch.equal(out, ref), (b, views)
+
+
+def test_batch_of_32_ragged_rows_matches_oracle():
+    """32 rows in one generate(): two MFMA B-operand tiles per weight fragment in every decode GEMV, 32-row prefill, sampler
+    and greedy state over 32 slots. Tokens must equal the CPU oracle's, pad fill included, and rows 16..31 must equal the
+    same rows run as a batch of 16."""
+    from oracle import cpu_ref as cr
+    from oracle_amd.dims import TINY
+    from oracle_amd.engine import Engine
+    from oracle_amd.llava.model.language_model.llava_llama import LlavaConfig, LlavaLlamaForCausalLM
+    from oracle_amd.synth import install_chain, synth_images, synth_state
+    st = install_chain(synth_state(TINY, seed=0), TINY)
+    eng = Engine(TINY, max_batch=32, max_seq=700, max_images=96, max_new_tokens=72)
+    eng.load_state(st)
+    model = LlavaLlamaForCausalLM(LlavaConfig(TINY, tokenizer_padding_side='left'), eng)
+    ids = _prompts(32)
+    imgs = synth_images(32, 3, TINY, seed=78)
+    out = model.generate(ids.cuda(), images=imgs.cuda(), do_sample=False, use_cache=True, max_new_tokens=70).cpu()
+    ref = cr.greedy_generate(st, TINY, ids, imgs, max_new_tokens=70)
+    assert torch.equal(out, ref)
+    half = model.generate(ids[16:].cuda(), images=imgs[16:].cuda(), max_new_tokens=70).cpu()
+    L = ids.shape[1]
+    n = min(half.shape[1], out.shape[1])
+    assert torch.equal(half[:, L:n], out[16:, L:n])
+    eng.close()

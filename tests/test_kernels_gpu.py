@@ -20,7 +20,7 @@ def _rand(shape, seed, scale=1.0):
     return (torch.randn(shape, generator=g) * scale).to(torch.bfloat16)
 
 
-@pytest.mark.parametrize('use_gemv,M', [(False, 300), (False, 128), (False, 1), (True, 1), (True, 8), (True, 16)])
+@pytest.mark.parametrize('use_gemv,M', [(False, 300), (False, 128), (False, 1), (True, 1), (True, 8), (True, 16), (True, 17), (True, 32)])
 @pytest.mark.parametrize('epi', ['none', 'quickgelu', 'gelu', 'residual', 'swiglu', 'f32'])
 def test_gemm_epilogues(use_gemv, M, epi):
     from oracle_amd import engine as E
@@ -181,7 +181,7 @@ def test_gemm_mixed_tile_heights_bitwise(epi):
         assert torch.equal(v, outs['dma256']), k
 
 
-@pytest.mark.parametrize('B,H', [(2, 32), (6, 32), (8, 32), (16, 32), (16, 12), (1, 32), (3, 4)])
+@pytest.mark.parametrize('B,H', [(2, 32), (6, 32), (8, 32), (16, 32), (16, 12), (1, 32), (3, 4), (32, 32), (21, 4)])
 def test_decode_attention_split_and_unsplit_branches(B, H):
     """Decode attention over the KV cache through the engine's own launch: B*H in {64, 192, 256, 512, ...} covers the
     split + combine path (B*H < 192) and the un-split single-workgroup path the batch-8 headline runs (8 x 32 = 256),
@@ -210,7 +210,7 @@ def test_decode_attention_split_and_unsplit_branches(B, H):
         assert torch.equal(out[-1].view(H, 128), vc[-1, :, n_keys - 1])
 
 
-@pytest.mark.parametrize('M', [1, 8, 16])
+@pytest.mark.parametrize('M', [1, 8, 16, 24, 32])
 @pytest.mark.parametrize('epi,N,K', [('swiglu', 22016, 4096), ('f32', 32000, 4096), ('residual', 4096, 11008), ('none', 12288, 4096)])
 def test_decode_gemv_at_llama7b_shapes(epi, N, K, M):
     """The decode GEMVs at the real LLaMA-7B shapes and 1 / 8 / 16 live rows: gate/up (688 units) and lm_head (1000 units)
@@ -236,3 +236,6 @@ def test_decode_gemv_at_llama7b_shapes(epi, N, K, M):
     if M > 1:
         one = E.test_gemm(x[:1].to(d), w.to(d), None, None if res is None else res[:1].to(d), epi, use_gemv=True).cpu()
         assert torch.equal(one[0], out[0])
+    if M > 16:       # rows of the second MFMA B tile: the same bits as when they run alone as rows 0..M-17
+        tail = E.test_gemm(x[16:].to(d), w.to(d), None, None if res is None else res[16:].to(d), epi, use_gemv=True).cpu()
+        assert torch.equal(tail, out[16:])

@@ -101,7 +101,7 @@ def test_stream_16_rows_over_32_slots_equals_generate():
     from oracle_amd.llava.model.language_model.llava_llama import LlavaConfig, LlavaLlamaForCausalLM
     from oracle_amd.synth import install_chain, synth_state
     st = install_chain(synth_state(TINY, seed=0), TINY)
-    eng = Engine(TINY, max_batch=32, max_seq=700, max_images=80, max_new_tokens=48)
+    eng = Engine(TINY, max_batch=32, max_seq=700, max_images=128, max_new_tokens=48)
     eng.load_state(st)
     model = LlavaLlamaForCausalLM(LlavaConfig(TINY, tokenizer_padding_side='left'), eng)
     items = _batches([8, 8, 8, 5, 8, 3, 8], seed=21)
@@ -109,6 +109,9 @@ def test_stream_16_rows_over_32_slots_equals_generate():
     refs = [model.generate(it['input_ids'], images=it['images'], max_new_tokens=40).cpu() for it in items]
     for k, (o, r) in enumerate(zip(outs, refs)):
         assert torch.equal(o, r), k
-    with pytest.raises(Exception, match='16'):
-        model.generate(torch.cat([items[0]['input_ids']] * 3), images=torch.cat([items[0]['images']] * 3), max_new_tokens=4)
+    outs32 = [o.cpu() for o in model.generate_stream(iter(items), max_new_tokens=40, n_rows=32, chunk=4)]   # 32 rows: all slots decode
+    for k, (o, r) in enumerate(zip(outs32, refs)):
+        assert torch.equal(o, r), k
+    with pytest.raises(Exception, match='32'):
+        model.generate(torch.cat([items[0]['input_ids']] * 5), images=torch.cat([items[0]['images']] * 5), max_new_tokens=4)
     eng.close()
