@@ -142,6 +142,39 @@ def cpu_point():
     return res
 
 
+def eager_gpu_point(a):
+    """The same workload through the ORACLE's torch code executed by PyTorch-ROCm eager on this GPU (bf16): op for op what the
+    reference's own stack (HF eager attention, torch.cat KV cache, one kernel per op, rocBLAS/hipBLASLt GEMMs) runs on an
+    MI355X. A reported baseline beside the CPU one, not part of the default run and never the thing shipped
+    (python bench.py --eager-point [--batch 8 --views 3 --new-tokens 150])."""
+    import torch
+    from oracle import cpu_ref as cr
+    from oracle_amd import synth
+    from oracle_amd.dims import FULL
+    from oracle_amd.tokenizer import SynthTokenizer
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(1234)
+    st = synth.synth_state(FULL, seed=0, device=dev, device_fast=True)
+    ids, images = build_inputs(SynthTokenizer(FULL.vocab), a.batch, a.views, FULL, dev, a.prompt)
+    mv = 'learned' if a.views > 1 else 'concat'
+    times = []
+    with torch.inference_mode(), torch.device(dev):
+        for rep in range(1 + max(a.steps, 1)):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = cr.greedy_generate(st, FULL, ids, images, mv_type=mv, max_new_tokens=a.new_tokens if rep else 4, eos_token_id=-1)
+            torch.cuda.synchronize()
+            if rep:
+                times.append(time.perf_counter() - t0)
+    assert out.shape[1] - ids.shape[1] == a.new_tokens
+    dt = sum(times) / len(times)
+    res = {'config': f'{a.views}-view ORacle LLaVA-7B, batch {a.batch}, {a.prompt} prompt, greedy decode {a.new_tokens} new tokens/frame, bf16, '
+                     'oracle/cpu_ref.py executed by torch eager on the GPU (the reference\'s arithmetic and op granularity)',
+           'frames_per_s': a.batch / dt, 'ms_per_step': dt * 1e3, 'steps': len(times), 'torch': torch.__version__}
+    print(json.dumps({'eager_gpu_point': res}), flush=True)
+    return res
+
+
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
     (profiles/: FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 x2 read correction already applied by
@@ -302,6 +335,8 @@ def main():
     ap.add_argument('--ragged-batches', type=int, default=16)
     ap.add_argument('--cpu-point', action='store_true',
                     help='time BASELINE configs[0] for real on the host cores (full-size fp32 CPU oracle, ~30 GB RAM, ~1 min) and exit')
+    ap.add_argument('--eager-point', action='store_true',
+                    help="time the same workload through the oracle's torch code run eager on the GPU (what the reference's stack does) and exit")
     ap.add_argument('--dry-run', action='store_true',
                     help='launcher / rendezvous / gather / max-over-ranks plumbing only (no GPU, no engine): CPU test of the N>1 path')
     a = ap.parse_args()
@@ -316,6 +351,8 @@ def main():
         return dry_run(a)
     if a.cpu_point:
         return cpu_point()
+    if a.eager_point:
+        return eager_gpu_point(a)
 
     import torch
     import torch.distributed as dist
@@ -448,13 +485,17 @@ def main():
                                'prefill': {'flops': fl_pre, 'achieved_TFLOPs': fl_pre / t_pre / 1e12, 'frac': fl_pre / t_pre / 1e12 / MFMA_PEAK_TFLOPS}},
             'decode_step': {'algorithmic_bytes': dec_bytes, 'achieved_GBps': dec_bytes / (dec_ms * 1e-3) / 1e9,
                             'frac_of_hbm_peak': dec_bytes / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-            'roofline': {'kernel': 'gemv_pers_kernel<2,SWIGLU,12,1> (decode gate/up projection, 22016x4096 bf16 weights)', 'bound': 'hbm',
+            'roofline': {'kernel': 'gemv_pers_kernel<2,SWIGLU,12,1,1> (decode gate/up projection, 22016x4096 bf16 weights)', 'bound': 'hbm',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'traffic_source': traffic_src, 'launches_timed': prof_n, 'avg_launch_us': avg_us,
                          'algorithmic_bytes_per_launch': prof_bytes},
         }
         if ragged is not None:
             res['extra'] = {'ragged': ragged}
+        eager = os.path.join(ROOT, 'profiles', 'r2', 'eager_gpu_point.json')
+        if os.path.exists(eager) and a.dims == 'full':   # a recorded point (python bench.py --eager-point), not measured in this run
+            res.setdefault('extra', {})['reference_stack_on_mi355x'] = dict(json.load(open(eager))['eager_gpu_point'], source='profiles/r2/eager_gpu_point.json',
+                                                                             note='recorded separately at batch 8 x 3 views x 150 tokens; not measured in this run')
         if check is not None:
             res['self_check'] = check['result']
             res['self_check_detail'] = check
