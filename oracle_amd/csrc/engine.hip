@@ -388,12 +388,14 @@ extern "C" int orc_engine_finalize(orc_engine* e) {
     const int t = pr / 32, wi = pr % 32;   // gate tile, up tile alternate every 16 rows
     gu_map[pr] = wi < 16 ? 16 * t + wi : c.d_ff + 16 * t + (wi - 16);
   }
-  // decode copy of the fused q/k/v weight: inside every 128-row head section tile j is followed by tile j+4, so one
-  // workgroup of the decode GEMV holds a head dim and its rotary partner (d, d+64) in the same lane
+  // decode copy of the fused q/k/v weight, in units of three 16-row tiles: tile j and tile j+4 of a q or k head (so one
+  // workgroup of the decode GEMV holds a head dim and its rotary partner (d, d+64) in the same lane) followed by one tile
+  // of the v projection. There are 8 * n_heads rotary pairs and as many v tiles: d_model / 16 units of equal work (256 for
+  // the 7B model: one workgroup per CU), unit u = pair u of the q|k sections + v rows [16u, 16u + 16).
   std::vector<int> qkv_dec_map(3 * c.d_model);
   for (int pr = 0; pr < 3 * c.d_model; ++pr) {
-    const int p = pr / 16, rr = pr % 16, pair = p / 2, which = p % 2, hs = pair / 4, j = pair % 4;
-    qkv_dec_map[pr] = hs * 128 + (j + 4 * which) * 16 + rr;
+    const int unit = pr / 48, tile = (pr % 48) / 16, rr = pr % 16, hs = unit / 4, j = unit % 4;
+    qkv_dec_map[pr] = tile < 2 ? hs * 128 + (j + 4 * tile) * 16 + rr : 2 * c.d_model + unit * 16 + rr;
   }
   for (int i = 0; i < c.n_layers; ++i) {
     snprintf(buf, sizeof(buf), "model.layers.%d.", i);

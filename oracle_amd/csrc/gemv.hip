@@ -82,7 +82,7 @@ __device__ __forceinline__ float scale_of_row(const GemvArgs& a, const float (*s
 template <int NT, int EPI, int WAVES, int RH>
 __device__ __forceinline__ void epilogue_pair(const GemvArgs& a, const float (*red)[NT][RH][64][4], int pair, int lane,
                                               const float (*sh_ps)[RH][64]) {
-  static_assert(NT == 2, "paired tiles");
+  static_assert(NT == 2 || (NT == 3 && EPI == EPI_ROPE_KV), "paired tiles (+ one V tile for the q/k/v projection)");
   constexpr int SW = WAVES < 4 ? WAVES : 4;
   const int g = lane >> 4;
 #pragma unroll
@@ -149,6 +149,30 @@ __device__ __forceinline__ void epilogue_pair(const GemvArgs& a, const float (*r
       *(u32x2*)dst = s0;
       *(u32x2*)(dst + 64) = s1;
     }
+  }
+}
+
+// Third tile of a q/k/v unit: 16 dims of the V projection (no rotary) -> V cache. Unit u carries V tile u, i.e. dims
+// [16 * (u % 8), +16) of head u / 8.
+template <int NT, int WAVES, int RH>
+__device__ __forceinline__ void epilogue_vtile(const GemvArgs& a, const float (*red)[NT][RH][64][4], int unit, int lane,
+                                               const float (*sh_ps)[RH][64]) {
+  constexpr int SW = WAVES < 4 ? WAVES : 4;
+  const int g = lane >> 4;
+#pragma unroll
+  for (int hf = 0; hf < RH; ++hf) {
+    const int b = (lane & 15) + 16 * hf;
+    f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < WAVES; ++i) t += *(const f32x4*)&red[i][2][hf][lane][0];
+    if (b >= a.M) continue;
+    if (a.ssq_in) t *= scale_of_row<SW, RH>(a, sh_ps, hf, lane & 15);
+    const int sl = a.map.slot[b];
+    if (sl < 0) continue;
+    const int h = unit >> 3, d = (unit & 7) * 16 + 4 * g;
+    const int slot = a.cur_len[sl] - 1;
+    u32x2 st = {pack2(t[0], t[1]), pack2(t[2], t[3])};
+    *(u32x2*)(a.Vc + (size_t)sl * a.c_bs + (size_t)h * a.c_hs + (size_t)slot * 128 + d) = st;
   }
 }
 
@@ -311,6 +335,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs a) {
 
   if constexpr (EPI == EPI_SWIGLU || EPI == EPI_ROPE_KV) {
     if (w == 0) epilogue_pair<NT, EPI, WAVES, RH>(a, red, blockIdx.x, lane, sh_ps);
+    if constexpr (NT == 3) {
+      if (w == (WAVES > 1 ? 1 : 0)) epilogue_vtile<NT, WAVES, RH>(a, red, blockIdx.x, lane, sh_ps);
+    }
   } else {
     if (w < NT) epilogue_tile<NT, EPI, WAVES, RH>(a, red, w, ntile0 + w, lane, sh_ps);
   }
@@ -407,6 +434,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_pers_kernel(GemvArgs a, int u
             const int unit = blockIdx.x + cj * G;
             if constexpr (EPI == EPI_SWIGLU || EPI == EPI_ROPE_KV) {
               epilogue_pair<NT, EPI, WAVES, RH>(a, rp, unit, lane, sh_ps);
+              if constexpr (NT == 3) epilogue_vtile<NT, WAVES, RH>(a, rp, unit, lane, sh_ps);
             } else {
 #pragma unroll
               for (int nt = 0; nt < NT; ++nt) epilogue_tile<NT, EPI, WAVES, RH>(a, rp, nt, unit * NT + nt, lane, sh_ps);
@@ -456,7 +484,8 @@ void go(const GemvArgs& a, int ntiles, hipStream_t s) {
 // Tuned on MI355X with tools/decode_bench (M = 8, LLaMA-7B shapes). Shallow load queues win everywhere (deeper unrolls
 // oversubscribe the memory system: -10..-25 %); about 8 MiB in flight over the chip is the sweet spot.
 //   o, down (residual epilogue, N = 4096: 256 units)   one unit per workgroup, K split 16 ways
-//   qkv + rotary (384 units)                           one unit per workgroup, 4 waves, one k-tile per buffer (20.1 -> 18.8 us)
+//   qkv + rotary (256 units of 3 tiles: a rotary pair  one unit per workgroup, K split 8 ways, two k-tiles per buffer
+//   of q or k + one v tile)                            (384 two-tile units on 4 waves: 18.8 us; 256 balanced units: 18.1 us)
 //   gate/up (688), lm_head (1000)                      persistent: ceil(units / 256) units per workgroup, 12 / 8 waves
 //                                                      (30.8 -> 29.4 us, 41.4 -> 40.3 us)
 // Tried and removed: RMSNorm in the prologue of the persistent kernel (row scales from the partials, activation image in
@@ -470,7 +499,8 @@ hipError_t pick_default(const GemvArgs& a, int ntiles, hipStream_t s) {
   // The K split (number of waves) depends on the SHAPE only, never on the row count: the fp32 summation order, and with
   // it every output bit of a row, is the same alone and inside any batch.
   if (units <= 256 || KT < 12) {
-    if (units <= 256) go<NT, EPI, 16, 1, 1>(a, ntiles, s);
+    if (units <= 256 && EPI == EPI_ROPE_KV && KT >= 16) go<NT, EPI, 8, 2, 1>(a, ntiles, s);   // 3-tile units: 18.1 vs 18.4 us
+    else if (units <= 256) go<NT, EPI, 16, 1, 1>(a, ntiles, s);
     else go<NT, EPI, 4, 2, 1>(a, ntiles, s);
   } else if constexpr (EPI == EPI_ROPE_KV) {
     go_pers<NT, EPI, 4, 1>(a, ntiles, units, s);
@@ -521,7 +551,7 @@ hipError_t launch_gemv_ex(const GemvArgs& a, int epi, int variant, hipStream_t s
     case EPI_GELU: return pick<1, EPI_GELU>(a, ntiles, variant, s);
     case EPI_RESIDUAL: return pick<1, EPI_RESIDUAL>(a, ntiles, variant, s);
     case EPI_SWIGLU: return pick<2, EPI_SWIGLU>(a, ntiles, variant, s);
-    case EPI_ROPE_KV: return pick<2, EPI_ROPE_KV>(a, ntiles, variant, s);
+    case EPI_ROPE_KV: return pick<3, EPI_ROPE_KV>(a, ntiles, variant, s);
     case EPI_F32: return (ntiles % 2 == 0) ? pick<2, EPI_F32>(a, ntiles, variant, s) : pick<1, EPI_F32>(a, ntiles, variant, s);
   }
   return hipErrorInvalidValue;
@@ -540,8 +570,8 @@ hipError_t pick_pers(const GemvArgs& a, int ntiles, int waves, int u, int grid, 
     case 82: go_pers<NT, EPI, 8, 2>(a, ntiles, grid, s); break;
     case 121: go_pers<NT, EPI, 12, 1>(a, ntiles, grid, s); break;
     case 122: go_pers<NT, EPI, 12, 2>(a, ntiles, grid, s); break;
-    case 161: go_pers<NT, EPI, 16, 1>(a, ntiles, grid, s); break;
-    case 162: go_pers<NT, EPI, 16, 2>(a, ntiles, grid, s); break;
+    case 161: if constexpr (NT < 3) { go_pers<NT, EPI, 16, 1>(a, ntiles, grid, s); break; } else return hipErrorInvalidValue;   // LDS
+    case 162: if constexpr (NT < 3) { go_pers<NT, EPI, 16, 2>(a, ntiles, grid, s); break; } else return hipErrorInvalidValue;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -553,7 +583,7 @@ hipError_t launch_gemv_pers(const GemvArgs& a, int epi, int waves, int u, int gr
   switch (epi) {
     case EPI_RESIDUAL: return pick_pers<1, EPI_RESIDUAL>(a, ntiles, waves, u, grid, s);
     case EPI_SWIGLU: return pick_pers<2, EPI_SWIGLU>(a, ntiles, waves, u, grid, s);
-    case EPI_ROPE_KV: return pick_pers<2, EPI_ROPE_KV>(a, ntiles, waves, u, grid, s);
+    case EPI_ROPE_KV: return pick_pers<3, EPI_ROPE_KV>(a, ntiles, waves, u, grid, s);
     case EPI_F32: return pick_pers<2, EPI_F32>(a, ntiles, waves, u, grid, s);
   }
   return hipErrorInvalidValue;

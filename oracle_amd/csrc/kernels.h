@@ -43,7 +43,7 @@ struct GemvArgs {
   int M, N, K, Nvalid;
   // EPI_RESIDUAL: when non-null, ssq_out[b * (N/16) + ntile] = sum of squares of the stored tile values of row b
   float* ssq_out;
-  // EPI_ROPE_KV: W rows packed per head-section as (tile j, tile j+4) pairs; C = q output [M][H*128]
+  // EPI_ROPE_KV: W rows packed in units of 3 tiles: (tile j, tile j+4) of a q or k head, then one v tile; C = q output [M][H*128]
   int H; const int* kbeg; const int* cur_len;   // per SLOT: first valid key; cached keys incl. the token of this step
   RowMap map;                                   // decode row -> slot (state and cache rows)
   const bf16_t* cos_tab; const bf16_t* sin_tab; int maxpos;

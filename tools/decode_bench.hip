@@ -161,7 +161,7 @@ int main(int argc, char** argv) {
       a.H = H; a.kbeg = ints + 16; a.cur_len = ints; a.cos_tab = cosb; a.sin_tab = sinb;
       a.maxpos = 4096; a.Kc = Kc; a.Vc = Vc; a.c_bs = (long)H * Tmax * 128; a.c_hs = (long)Tmax * 128;
       a.ssq_out = ssq;
-      const int units = sh.N / 16 / (sh.epi == EPI_RESIDUAL ? 1 : 2);
+      const int units = sh.N / 16 / (sh.epi == EPI_RESIDUAL ? 1 : (sh.epi == EPI_ROPE_KV ? 3 : 2));
       // reference output with the default kernel on fixed weights
       const size_t out_bytes = (size_t)16 * 32000 * 4;
       std::vector<char> ref(out_bytes), got(out_bytes);
