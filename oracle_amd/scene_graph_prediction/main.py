@@ -47,6 +47,8 @@ def main(argv=None):
     ap.add_argument('--image_size', type=str, default='336x336', help='synthetic camera image size WxH (4D-OR: 2048x1536)')
     ap.add_argument('--image_format', type=str, default='png', choices=['png', 'jpg'], help='synthetic camera image files')
     ap.add_argument('--decode_workers', type=int, default=None, help='image-decode threads (0: decode in the main thread, as the reference)')
+    ap.add_argument('--kv_slots', type=int, default=None,
+                    help='KV-cache slots of the engine (default 32: 16 frames decode while 16 wait prefilled; 64: 32 + 32)')
     args = ap.parse_args(argv)
     seed_everything(42)
     config = config_loader(args.config)
@@ -68,7 +70,8 @@ def main(argv=None):
     model = OracleWrapper(config, num_class=len(eval_dataset.classNames), num_rel=len(eval_dataset.relationNames),
                           weights_obj=train_dataset.w_cls_obj, weights_rel=train_dataset.w_cls_rel,
                           relationNames=train_dataset.relationNames, model_path=args.model_path, mv_desc=mv_desc,
-                          **({} if args.decode_workers is None else {'decode_workers': args.decode_workers}))
+                          **({} if args.decode_workers is None else {'decode_workers': args.decode_workers}),
+                          **({} if args.kv_slots is None else {'max_batch': args.kv_slots}))
     takes = [int(s.split('_')[0]) for s in eval_dataset.scans]
     mine = parallel.shard_indices(len(eval_dataset), rank, world, groups=takes if temporal else None)
     results = model.validate(batches(eval_dataset, batch_size, mine), return_raw_predictions=True, report=world == 1)

@@ -1,7 +1,7 @@
 """GPU box: the drop-in CLI end to end at full size on the synthetic dataset (host image decode, upload, device
 preprocessing, tokenisation, generate() / generate_stream(), answer parsing, metrics): wall-clock frames/s including
 everything the bench leaves out.
-usage: cli_e2e.py [frames] [model] [WxH] [png|jpg] [decode_workers] [stream 0|1]
+usage: cli_e2e.py [frames] [model] [WxH] [png|jpg] [decode_workers] [stream 0|1] [kv_slots]
   e.g. cli_e2e.py 64 synthetic:full 2048x1536 jpg 0 0   -> the reference's behaviour: serial decode in the main thread, batch by batch
        cli_e2e.py 64 synthetic:full 2048x1536 jpg 8 1   -> decode threads + continuous batching"""
 import os
@@ -18,6 +18,7 @@ size = sys.argv[3] if len(sys.argv) > 3 else '336x336'
 fmt = sys.argv[4] if len(sys.argv) > 4 else 'png'
 workers = sys.argv[5] if len(sys.argv) > 5 else None
 stream = (sys.argv[6] != '0') if len(sys.argv) > 6 else True
+slots = sys.argv[7] if len(sys.argv) > 7 else None
 os.chdir('/tmp')
 t = {'val': 0.0, 'decode': 0.0}
 orig_validate = wmod.OracleWrapper.validate
@@ -50,12 +51,14 @@ wmod.OracleWrapper.__init__ = init
 argv = ['--config', 'oracle_mv_learned.json', '--model_path', model, '--limit_frames', str(n), '--image_size', size, '--image_format', fmt]
 if workers is not None:
     argv += ['--decode_workers', workers]
+if slots is not None:
+    argv += ['--kv_slots', slots]
 # first pass writes the image files and warms the engine up; the second is timed
 cli.main(argv)
 t['val'] = t['decode'] = 0.0
 s0 = time.perf_counter()
 res = cli.main(argv)
 wall = time.perf_counter() - s0
-print(f'frames {len(res)}  images {size} {fmt}  decode_workers {workers}  stream {stream}: validate() {t["val"]:.2f}s = '
+print(f'frames {len(res)}  images {size} {fmt}  decode_workers {workers}  stream {stream}  kv_slots {slots}: validate() {t["val"]:.2f}s = '
       f'{len(res) / t["val"]:.2f} frames/s host-inclusive  (image decode, summed over threads: {t["decode"]:.2f}s; '
       f'whole CLI call incl. model build {wall:.1f}s)')

@@ -20,9 +20,10 @@ int main(int argc, char** argv) {
       {"prefill gu swiglu", Mp, 22016, 4096, EPI_SWIGLU}, {"prefill down+res ", Mp, 4096, 11008, EPI_RESIDUAL},
       {"vit qkv          ", Mv, 3072, 1024, EPI_NONE}, {"vit o +res       ", Mv, 1024, 1024, EPI_RESIDUAL},
       {"vit fc1 quickgelu", Mv, 4096, 1024, EPI_QUICKGELU}, {"vit fc2 +res     ", Mv, 1024, 4096, EPI_RESIDUAL},
+      {"square 4096      ", 4096, 4096, 4096, EPI_NONE}, {"square 8192      ", 8192, 8192, 8192, EPI_NONE},   // the guide's template shapes
   };
   bf16_t *X, *W, *R, *C, *bias;
-  CK(hipMalloc((void**)&X, (size_t)Mv * 11008 * 2)); CK(hipMalloc((void**)&W, (size_t)22016 * 4096 * 2 * 2));
+  CK(hipMalloc((void**)&X, (size_t)Mv * 11008 * 2)); CK(hipMalloc((void**)&W, (size_t)22016 * 4096 * 2 * 2));   // X >= 8192 x 8192, W >= 2 x 8192 x 8192
   CK(hipMalloc((void**)&R, (size_t)Mv * 4096 * 2)); CK(hipMalloc((void**)&C, (size_t)Mv * 12288 * 2)); CK(hipMalloc((void**)&bias, 65536));
   hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, X, (size_t)Mv * 11008, 1u);
   hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, W, (size_t)22016 * 4096 * 2, 2u);
