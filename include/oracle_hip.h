@@ -160,9 +160,15 @@ int orc_test_decode_attention(const void* q, const void* kcache, const void* vca
  * the summed duration, the number of sampled launches and the algorithmic bytes of one launch. */
 int orc_profile_enable(orc_engine* e, int on);
 int orc_profile_read(orc_engine* e, double* total_ms, int32_t* count, int64_t* bytes_per_launch);
-/* bytes of weights streamed by one decode step / bytes of KV read per cached key per row (roofline bookkeeping). */
+/* ALGORITHMIC bytes of weights of one decode step (bf16: 2 N K per projection) / bytes of KV read per cached key per row
+ * (roofline bookkeeping). */
 int64_t orc_decode_weight_bytes(orc_engine* e);
 int64_t orc_kv_bytes_per_key(orc_engine* e);
+/* PHYSICAL weight bytes the decode kernels stream: the engine keeps lossless 12-bit copies of the decode weights (768 B per
+ * 1-KiB fragment block + 1 B per block, bit-exact decode in the GEMV; environment ORC_DECODE_WEIGHTS=plain turns it off).
+ * which = 0: one whole decode step; which = 1: one gate/up launch (the kernel orc_profile_read samples). No counterpart in the
+ * reference (measurement only). */
+int64_t orc_decode_stream_bytes(orc_engine* e, int which);
 
 #ifdef __cplusplus
 }

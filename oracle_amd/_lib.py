@@ -59,6 +59,7 @@ SYMBOLS = {
     'orc_profile_read': (_I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(_L)]),
     'orc_decode_weight_bytes': (_L, [_P]),
     'orc_kv_bytes_per_key': (_L, [_P]),
+    'orc_decode_stream_bytes': (_L, [_P, _I]),
 }
 
 

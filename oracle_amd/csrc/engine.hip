@@ -2,6 +2,7 @@
 // workspace pre-allocated, every stage a short sequence of the kernels in gemm/gemv/attn/norm/misc.hip.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -42,6 +43,8 @@ struct Raw {
 struct Packed {
   bf16_t* p = nullptr;
   int N = 0, K = 0, Nvalid = 0;   // padded rows / cols, valid rows
+  // lossless 12-bit copy for the decode GEMVs (gemv.hip); null = the GEMV streams p
+  uint8_t* wc = nullptr; uint8_t* emin = nullptr; uint16_t* patch = nullptr;
 };
 struct ClipLayer {
   bf16_t *ln1w, *ln1b, *ln2w, *ln2b, *bqkv, *bo, *b1, *b2;
@@ -110,6 +113,7 @@ struct orc_engine {
   int *dev_ints = nullptr;   // [0]=step [2]=n_unfinished, then per-row arrays of 16 (DI_* offsets), then the token buffer
   int *d_step, *d_nunf, *d_unf, *d_next, *d_argmax, *d_kbeg, *d_kend, *d_rowoff, *d_rowvalid, *d_curlen, *d_rowstep, *d_limit, *d_tokens;
   int* d_pfkbeg = nullptr;   // [16] left pad of the rows of the prefill being launched (attention reads it per launch row)
+  bool compress_decode = true;   // ORC_DECODE_WEIGHTS=plain turns the 12-bit decode copies off (A/B runs)
   bool stream_mode = false;  // continuous batching (orc_stream_begin): decode rows are re-pointed at slots prefilled ahead
   RowMap row_map;            // decode row -> slot (host copy; goes to the kernels by value)
   int cur_batch = 0, cur_T = 0;
@@ -237,6 +241,43 @@ int gemm(const bf16_t* X, int ldx, const Packed& W, const bf16_t* bias, const bf
   a.Nvalid = (epi == EPI_SWIGLU) ? W.Nvalid / 2 : W.Nvalid;
   hipError_t err = small ? launch_gemv(a, epi, s) : launch_gemm(a, epi, s);
   if (err != hipSuccess) return fail(small ? "launch_gemv" : "launch_gemm", hipGetErrorString(err));
+  return 0;
+}
+
+void free_owned(orc_engine* e, void* p) {
+  if (!p) return;
+  for (auto& o : e->owned)
+    if (o == p) { (void)hipFree(o); o = nullptr; }
+}
+
+// Decode GEMVs are HBM-bound on the weight stream and their vector ALUs idle: give W a lossless 12-bit copy (768 B per 1-KiB
+// fragment block, bit-exact decode in the kernel, gemv.hip) that the decode launches stream instead. epi = the epilogue the
+// decode GEMV of this matrix runs with (it fixes the unit size of the patch tables). drop_plain: the bf16 copy is used by
+// nothing else (the norm-folded decode copies) and is freed. A matrix with a unit of more than 256 out-of-range elements
+// (never seen with Gaussian or trained weights; possible with crafted ones) silently stays uncompressed.
+int compress_for_decode(orc_engine* e, Packed* W, int epi, bool drop_plain) {
+  if (!e->compress_decode || !W->p) return 0;
+  const int nt_unit = gemv_unit_tiles(epi, W->N);
+  const size_t nblk = (size_t)(W->N / 16) * (W->K / 32);
+  const int units = W->N / 16 / nt_unit;
+  uint8_t *wc = nullptr, *em = nullptr;
+  uint16_t* patch = nullptr;
+  int* cnt = nullptr;
+  ORCCHK(e->alloc((void**)&wc, nblk * 768));
+  ORCCHK(e->alloc((void**)&em, (nblk + 7) & ~(size_t)3));
+  ORCCHK(e->alloc((void**)&patch, (size_t)units * 256 * 2));
+  HIPCHK(hipMalloc((void**)&cnt, (size_t)(units + 1) * 4));
+  HIPCHK(hipMemset(cnt + units, 0, 4));
+  HIPCHK(launch_compress_weight(W->p, W->N, W->K, nt_unit, wc, em, patch, cnt, cnt + units, 0));
+  int overflow = 0;
+  HIPCHK(hipMemcpy(&overflow, cnt + units, 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipFree(cnt));
+  if (overflow) {
+    free_owned(e, wc); free_owned(e, em); free_owned(e, patch);
+    return 0;
+  }
+  W->wc = wc; W->emin = em; W->patch = patch;
+  if (drop_plain) { free_owned(e, W->p); W->p = nullptr; }
   return 0;
 }
 
@@ -382,6 +423,11 @@ extern "C" int orc_engine_finalize(orc_engine* e) {
   ORCCHK(pack_rows(e, {"lm_head.weight"}, c.d_model, nullptr, 256, &e->lm_head));
   ORCCHK(pack_rows(e, {"lm_head.weight"}, c.d_model, nullptr, 256, &e->lm_head_dec, e->final_norm));
   free_raw(e, {"lm_head.weight"});
+  {
+    const char* m = getenv("ORC_DECODE_WEIGHTS");
+    e->compress_decode = !(m && strcmp(m, "plain") == 0);
+  }
+  ORCCHK(compress_for_decode(e, &e->lm_head_dec, EPI_F32, true));
   e->llama.resize(c.n_layers);
   std::vector<int> gu_map(2 * c.d_ff);
   for (int pr = 0; pr < 2 * c.d_ff; ++pr) {
@@ -411,6 +457,10 @@ extern "C" int orc_engine_finalize(orc_engine* e) {
     ORCCHK(pack_rows(e, w2, c.d_model, &gu_map, 256, &L.gu));
     ORCCHK(pack_rows(e, w2, c.d_model, &gu_map, 256, &L.gu_dec, L.ln_post));
     ORCCHK(pack_rows(e, {q + "mlp.down_proj.weight"}, c.d_ff, nullptr, 256, &L.down));
+    ORCCHK(compress_for_decode(e, &L.qkv_dec, EPI_ROPE_KV, true));
+    ORCCHK(compress_for_decode(e, &L.gu_dec, EPI_SWIGLU, true));
+    ORCCHK(compress_for_decode(e, &L.o, EPI_RESIDUAL, false));      // the prefill GEMM keeps reading the bf16 copy
+    ORCCHK(compress_for_decode(e, &L.down, EPI_RESIDUAL, false));
     w3.push_back(q + "self_attn.o_proj.weight");
     w3.push_back(w2[0]);
     w3.push_back(w2[1]);
@@ -653,6 +703,7 @@ static int gemv_ex(orc_engine* e, const bf16_t* X, int ldx, const Packed& W, con
   a.ssq_in = ssq_in; a.n_part = c.d_model / 16; a.norm_d = c.d_model; a.norm_eps = c.rms_eps; a.C_xf = C_xf;
   a.map = e->row_map;
   a.X = X; a.ldx = ldx; a.Wp = W.p; a.bias = nullptr; a.R = R; a.ldr = ldc; a.C = C; a.ldc = ldc;
+  a.Wc = W.wc; a.emin = W.emin; a.patch = W.patch;
   a.M = M; a.N = W.N; a.K = W.K; a.Nvalid = (epi == EPI_SWIGLU) ? W.Nvalid / 2 : W.Nvalid;
   a.H = c.n_heads; a.kbeg = e->d_kbeg; a.cur_len = e->d_curlen; a.cos_tab = e->cos_tab; a.sin_tab = e->sin_tab;
   a.maxpos = e->maxpos; a.Kc = kc; a.Vc = vc; a.c_bs = e->c_bs; a.c_hs = e->c_hs;
@@ -977,6 +1028,17 @@ extern "C" int64_t orc_decode_weight_bytes(orc_engine* e) {
   const int64_t per_layer = (int64_t)4 * c.d_model * c.d_model + (int64_t)3 * c.d_model * c.d_ff + 2 * c.d_model;
   return 2 * (per_layer * c.n_layers + c.d_model + (int64_t)c.vocab * c.d_model);
 }
+static int64_t stream_bytes(const Packed& W) {
+  const int64_t nk = (int64_t)W.N * W.K;
+  return W.wc ? nk * 3 / 2 + nk / 512 : nk * 2;
+}
+extern "C" int64_t orc_decode_stream_bytes(orc_engine* e, int which) {
+  if (!e || !e->finalized || e->llama.empty()) return 0;
+  if (which == 1) return stream_bytes(e->llama[0].gu_dec);
+  int64_t t = stream_bytes(e->lm_head_dec) + (int64_t)2 * e->c.d_model;
+  for (const LlamaLayer& L : e->llama) t += stream_bytes(L.qkv_dec) + stream_bytes(L.o) + stream_bytes(L.gu_dec) + stream_bytes(L.down);
+  return t;
+}
 extern "C" int64_t orc_kv_bytes_per_key(orc_engine* e) { return (int64_t)2 * 2 * e->c.n_layers * e->c.d_model; }
 
 // ============================================================================ single-kernel hooks
@@ -1003,10 +1065,43 @@ extern "C" int orc_test_gemm(const void* x, int M, int K, const void* w, int N, 
   const int nout = epi == EPI_SWIGLU ? N / 2 : N;
   a.ldr = nout; a.C = out; a.ldc = nout; a.M = M; a.N = Np; a.K = Kp; a.Nvalid = nout;
   // use_gemv: 0 = GEMM (automatic kernel choice), 1 = decode GEMV, 2 = 128^2 register-staged GEMM, 3 / 4 = LDS-DMA GEMM with
-  // 256-row / 128-row tiles only, 100 + n = LDS-DMA GEMM with n 256-row m-tiles and 128-row tiles for the remaining rows
+  // 256-row / 128-row tiles only, 5 = decode GEMV on the lossless 12-bit copy of the weights (must equal 1 bit for bit),
+  // 100 + n = LDS-DMA GEMM with n 256-row m-tiles and 128-row tiles for the remaining rows
+  hipError_t err;
+  if (use_gemv == 5) {
+    const int nt_unit = gemv_unit_tiles(epi, Np), units = Np / 16 / nt_unit;
+    const size_t nblk = (size_t)(Np / 16) * (Kp / 32);
+    uint8_t *wc, *em;
+    uint16_t* patch;
+    int* cnt;
+    HIPCHK(hipMalloc((void**)&wc, nblk * 768));
+    HIPCHK(hipMalloc((void**)&em, (nblk + 7) & ~(size_t)3));
+    HIPCHK(hipMalloc((void**)&patch, (size_t)units * 256 * 2));
+    HIPCHK(hipMalloc((void**)&cnt, (size_t)(units + 1) * 4));
+    HIPCHK(hipMemsetAsync(cnt + units, 0, 4, s));
+    HIPCHK(launch_compress_weight(wp, Np, Kp, nt_unit, wc, em, patch, cnt, cnt + units, s));
+    int overflow = 0;
+    HIPCHK(hipMemcpyAsync(&overflow, cnt + units, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    err = hipSuccess;
+    if (!overflow) {
+      GemvArgs g = {};
+      g.map = identity_map();
+      g.X = a.X; g.ldx = a.ldx; g.Wp = nullptr; g.Wc = wc; g.emin = em; g.patch = patch; g.bias = a.bias; g.R = a.R; g.ldr = a.ldr;
+      g.C = a.C; g.ldc = a.ldc; g.M = a.M; g.N = a.N; g.K = a.K; g.Nvalid = a.Nvalid;
+      err = launch_gemv_ex(g, epi, 0, s);
+      HIPCHK(hipStreamSynchronize(s));
+    }
+    HIPCHK(hipFree(wc)); HIPCHK(hipFree(em)); HIPCHK(hipFree(patch)); HIPCHK(hipFree(cnt));
+    HIPCHK(hipFree(wp));
+    if (rm) HIPCHK(hipFree(rm));
+    if (overflow) return fail("orc_test_gemm", "weights not compressible: a unit has more than 256 out-of-range elements");
+    if (err != hipSuccess) return fail("orc_test_gemm", hipGetErrorString(err));
+    return 0;
+  }
   if (use_gemv >= 100) gemm_force_kernel(use_gemv);
   else if (use_gemv >= 2) gemm_force_kernel(use_gemv - 1);
-  hipError_t err = use_gemv == 1 ? launch_gemv(a, epi, s) : launch_gemm(a, epi, s);
+  err = use_gemv == 1 ? launch_gemv(a, epi, s) : launch_gemm(a, epi, s);
   gemm_force_kernel(0);
   if (err != hipSuccess) return fail("orc_test_gemm", hipGetErrorString(err));
   HIPCHK(hipStreamSynchronize(s));

@@ -28,6 +28,103 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 // (k order, MFMA sequence, reduction order) is the same for RH = 1 and RH = 2 and for any number of live rows.
 // Fragment-ordered activations of more than 16 rows are two 16-row images one after the other (common.h xf_off_rows).
 
+// ---- losslessly compressed weights (CW kernels). bf16 weights of one 16 x 32 fragment block span few binades: the high byte
+// of an element (sign, exponent bits 7..1) is stored as 4 bits -- sign and a 3-bit offset d from the block's base eh -- and the
+// low byte (exponent bit 0, mantissa) as it is, so a block is 768 B instead of 1 KiB and the decode GEMVs -- HBM-bound on the
+// weight stream -- move 25 % fewer bytes. The decode is exact (bit-for-bit the original bf16): a block covers the 16 binades
+// [2 eh, 2 eh + 15]; elements outside (zeros / tiny values under a large block maximum: ~1e-4 of Gaussian weights) are
+// "escaped": the block is flagged, its base is lowered by one step so that the lowest exponent code is free, and an
+// element with that code carries an 8-bit index (sign, mantissa) into the unit's patch table of true values.
+// Lane layout (12 B): L0, L1 = low bytes of elements 0-3, 4-7; H = the eight 4-bit fields, element k < 4 in nibble 2k,
+// element 4 + k in nibble 2k + 1. ~17 integer vector ops per lane and block:
+//   four high bytes at once: (x & 0x07070707) + eh * 0x01010101 + ((x & 0x08080808) << 4), then v_perm interleaves.
+typedef __attribute__((ext_vector_type(3))) uint32_t u32x3;
+struct CwReg { u32x3 c; };
+// the block's emin byte through the scalar (constant) path: the address is wave-uniform, so this is an s_load into an SGPR --
+// no vector-memory instruction (a per-lane byte load per block, or a per-unit gather, cost 2-4 us per launch) and the base
+// replication / escape test below become scalar work. `word` = the aligned dword holding the byte.
+typedef __attribute__((address_space(4))) const uint32_t cw_cu32;
+__device__ __forceinline__ uint32_t cw_base_word(const uint8_t* emin, size_t blk) {
+  return ((cw_cu32*)(uintptr_t)emin)[blk >> 2];
+}
+__device__ __forceinline__ uint32_t cw_base_byte(uint32_t word, size_t blk) { return (word >> (8 * (blk & 3))) & 0xffu; }
+__device__ __forceinline__ uint32_t cw_high4(uint32_t x, uint32_t eh4) {   // four 4-bit fields (one per byte) -> four high bytes
+  return ((x & 0x07070707u) + eh4) + ((x & 0x08080808u) << 4);
+}
+// e: the block's byte of GemvArgs::emin, wave-uniform (an SGPR: the base replication and the escape test are scalar work)
+__device__ __forceinline__ bf16x8 cw_decode(const CwReg& r, uint32_t e, const uint16_t* sh_patch) {
+  uint32_t eh4 = e & 0x7fu;
+  eh4 |= eh4 << 8;
+  eh4 |= eh4 << 16;
+  const uint32_t ha = cw_high4(r.c[2] & 0x0f0f0f0fu, eh4), hb = cw_high4((r.c[2] >> 4) & 0x0f0f0f0fu, eh4);
+  u32x4 t = {__builtin_amdgcn_perm(ha, r.c[0], 0x05010400u), __builtin_amdgcn_perm(ha, r.c[0], 0x07030602u),
+             __builtin_amdgcn_perm(hb, r.c[1], 0x05010400u), __builtin_amdgcn_perm(hb, r.c[1], 0x07030602u)};
+#if !defined(CW_ABLATE) || CW_ABLATE != 3
+  if (e & 0x80u) {                                                       // rare: this block has escaped elements
+    const uint32_t base = (e & 0x7fu) << 8;                            // exponent code 0 of this block: high byte eh, low bit 7 clear
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const uint32_t lo = t[p] & 0xffffu, hi = t[p] >> 16;
+      if ((lo & 0x7f80u) == base) t[p] = (t[p] & 0xffff0000u) | sh_patch[(lo & 0x7fu) | ((lo >> 8) & 0x80u)];
+      if ((hi & 0x7f80u) == base) t[p] = (t[p] & 0x0000ffffu) | ((uint32_t)sh_patch[(hi & 0x7fu) | ((hi >> 8) & 0x80u)] << 16);
+    }
+  }
+#endif
+  return __builtin_bit_cast(bf16x8, t);
+}
+// Compressor (orc_engine_finalize, once per matrix): one wave per 1-KiB block of the packed bf16 matrix. nt_unit = n-tiles per
+// GEMV unit (the patch table is per unit). cnt[unit] (zeroed by the caller) counts escapes; *overflow is set if a unit
+// has more than 256 of them (the caller then keeps the matrix uncompressed).
+__global__ __launch_bounds__(64) void cw_compress_kernel(const bf16_t* __restrict__ Wp, int KT, int nt_unit, uint8_t* __restrict__ Wc,
+                                                         uint8_t* __restrict__ emin, uint16_t* __restrict__ patch,
+                                                         int* __restrict__ cnt, int* __restrict__ overflow) {
+  const size_t blk = blockIdx.x;
+  const int lane = threadIdx.x;
+  const u32x4 v = *(const u32x4*)(Wp + blk * 512 + lane * 8);
+  uint32_t el[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { el[2 * j] = v[j] & 0xffffu; el[2 * j + 1] = v[j] >> 16; }
+  int emax = 0, emn = 255;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ex = (el[j] >> 7) & 0xff;
+    emax = ex > emax ? ex : emax;
+    emn = ex < emn ? ex : emn;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int a = __shfl_xor(emax, o, 64), b = __shfl_xor(emn, o, 64);
+    emax = a > emax ? a : emax;
+    emn = b < emn ? b : emn;
+  }
+  const int eh = emax > 15 ? (emax - 14) >> 1 : 0;                     // smallest eh with 2 eh + 15 >= emax
+  const bool flagged = emn < 2 * eh;                                   // some element lies below the block's 16 binades
+  const int unit = (int)(blk / KT) / nt_unit;
+  uint32_t lo[2] = {0u, 0u}, hn = 0u;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ex = (el[j] >> 7) & 0xff;
+    uint32_t low = el[j] & 0xffu, nib;
+    if (flagged && ex <= 2 * eh) {                                     // escaped: exponent code 0 + an index into the unit's patch table
+      const int idx = atomicAdd(&cnt[unit], 1);
+      if (idx < 256) patch[(size_t)unit * 256 + idx] = (uint16_t)el[j];
+      else *overflow = 1;
+      low = (uint32_t)idx & 0x7fu;
+      nib = ((uint32_t)idx >> 4) & 0x8u;
+    } else {
+      nib = ((el[j] >> 12) & 0x8u) | (uint32_t)((ex - 2 * eh) >> 1);
+    }
+    lo[j >> 2] |= low << (8 * (j & 3));
+    hn |= nib << (j < 4 ? 8 * j : 8 * (j - 4) + 4);
+  }
+  uint32_t* dst = (uint32_t*)(Wc + blk * 768 + lane * 12);
+  dst[0] = lo[0]; dst[1] = lo[1]; dst[2] = hn;
+  if (lane == 0) emin[blk] = (uint8_t)(eh | (flagged ? 0x80 : 0));
+}
+
+template <bool CW> struct WFrag { bf16x8 v; };
+template <> struct WFrag<true> { CwReg r; };
+
 // Row scales of the folded RMSNorm (GemvArgs::ssq_in). The n_part per-tile partials of every row are summed in a fixed
 // order that does not depend on the batch: lane (g, b) of scale wave w (the first SW = min(WAVES, 4) waves) owns the
 // contiguous slice [(g * SW + w) * per, + per) of row b, per = n_part / (4 * SW) <= 16. The loads are the FIRST loads a wave
@@ -245,12 +342,14 @@ __device__ __forceinline__ void x_pointers(const GemvArgs& a, int lane, const bf
   xstep = a.x_xf ? 512 : 32;   // elements between this lane's fragments of consecutive k-tiles
 }
 
-template <int NT, int EPI, int WAVES, int U, int KMODE, int RH>
+template <int NT, int EPI, int WAVES, int U, int KMODE, int RH, bool CW>
 __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs a) {
   __shared__ __attribute__((aligned(16))) float red[WAVES][NT][RH][64][4];
   constexpr int SW = WAVES < 4 ? WAVES : 4;
   __shared__ float sh_ps[SW][RH][64];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  __shared__ uint16_t sh_patch[CW ? 256 : 1];                        // CW: this unit's escaped values
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int KT = a.K >> 5;
   const int ntile0 = blockIdx.x * NT;
   ScaleRegs<RH> sc;
@@ -272,22 +371,36 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs a) {
   const bf16_t* wp[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) wp[nt] = a.Wp + (size_t)(ntile0 + nt) * KT * 512 + lane * 8;
+  const size_t blk0 = (size_t)ntile0 * KT;                           // CW: first block of this unit
 
-  bf16x8 wA[U][NT], wB[U][NT];
+  WFrag<CW> wA[U][NT], wB[U][NT];
   u32x4 xA[U][RH], xB[U][RH];
+  uint32_t eA[U][NT], eB[U][NT];                                     // CW: the blocks' emin bytes (SGPRs)
   // defined contents for the slots a short k-run never loads (their MFMAs are skipped by the same uniform branch;
   // leaving them undefined lets the compiler poison the accumulator)
 #pragma unroll
   for (int u = 0; u < U; ++u)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) wA[u][nt] = wB[u][nt] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-  auto wload = [&](bf16x8 (&dst)[U][NT], u32x4 (&xd)[U][RH], int i) {
+    for (int nt = 0; nt < NT; ++nt) {
+      eA[u][nt] = eB[u][nt] = 0u;
+      if constexpr (CW) { wA[u][nt].r.c = u32x3{0u, 0u, 0u}; wB[u][nt].r = wA[u][nt].r; }
+      else wA[u][nt].v = wB[u][nt].v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  auto wload = [&](WFrag<CW> (&dst)[U][NT], u32x4 (&xd)[U][RH], uint32_t (&ed)[U][NT], int i) {
 #pragma unroll
     for (int u = 0; u < U; ++u)
       if (i + u < nk) {   // wave-uniform: a real branch, the loads stay un-waited until their MFMA
         const int kt = k0 + (i + u) * kstep;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) dst[u][nt] = __builtin_nontemporal_load((const bf16x8*)(wp[nt] + (size_t)kt * 512));
+        for (int nt = 0; nt < NT; ++nt) {
+          if constexpr (CW) {
+            const size_t blk = blk0 + (size_t)nt * KT + kt;
+            dst[u][nt].r.c = __builtin_nontemporal_load((const u32x3*)(a.Wc + blk * 768 + lane * 12));
+            ed[u][nt] = cw_base_byte(cw_base_word(a.emin, blk), blk);
+          } else {
+            dst[u][nt].v = __builtin_nontemporal_load((const bf16x8*)(wp[nt] + (size_t)kt * 512));
+          }
+        }
       }
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -297,8 +410,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs a) {
         if (i + u < nk && row_ok[hf]) xd[u][hf] = *(const u32x4*)(xp[hf] + (size_t)(k0 + (i + u) * kstep) * xstep);
       }
   };
-  wload(wA, xA, 0);
-  wload(wB, xB, U);
+  wload(wA, xA, eA, 0);
+  wload(wB, xB, eB, U);
+  if constexpr (CW) {   // the unit's patch table, behind the first weight loads
+    if (tid < 256) sh_patch[tid] = a.patch[(size_t)blockIdx.x * 256 + tid];
+    __syncthreads();
+  }
 
   f32x4 acc[NT][RH];
 #pragma unroll
@@ -306,24 +423,30 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs a) {
 #pragma unroll
     for (int hf = 0; hf < RH; ++hf) acc[nt][hf] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  auto compute = [&](bf16x8 (&src)[U][NT], u32x4 (&xs)[U][RH], int i) {
+  auto compute = [&](WFrag<CW> (&src)[U][NT], u32x4 (&xs)[U][RH], uint32_t (&es)[U][NT], int i) {
 #pragma unroll
     for (int u = 0; u < U; ++u)
       if (i + u < nk) {
+        bf16x8 wf[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          if constexpr (CW) wf[nt] = cw_decode(src[u][nt].r, es[u][nt], sh_patch);
+          else wf[nt] = src[u][nt].v;
+        }
 #pragma unroll
         for (int hf = 0; hf < RH; ++hf) {
           const bf16x8 xf = __builtin_bit_cast(bf16x8, xs[u][hf]);
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) acc[nt][hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(src[u][nt], xf, acc[nt][hf], 0, 0, 0);
+          for (int nt = 0; nt < NT; ++nt) acc[nt][hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf, acc[nt][hf], 0, 0, 0);
         }
       }
   };
 
   for (int i = 0; i < nk; i += 2 * U) {
-    compute(wA, xA, i);
-    wload(wA, xA, i + 2 * U);
-    compute(wB, xB, i + U);
-    wload(wB, xB, i + 3 * U);
+    compute(wA, xA, eA, i);
+    wload(wA, xA, eA, i + 2 * U);
+    compute(wB, xB, eB, i + U);
+    wload(wB, xB, eB, i + 3 * U);
   }
 
 #pragma unroll
@@ -349,11 +472,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs a) {
 // At a unit boundary each wave parks its partial tiles in LDS (two parities), one barrier, and ONE wave (rotating)
 // runs the epilogue while the others are already multiplying the next unit. Bytes in flight per CU are set by
 // WAVES * 2 * U * NT KiB and not by how many workgroups happen to share the CU.
-template <int NT, int EPI, int WAVES, int U, int RH>
+template <int NT, int EPI, int WAVES, int U, int RH, bool CW>
 __global__ __launch_bounds__(WAVES * 64) void gemv_pers_kernel(GemvArgs a, int units) {
   __shared__ __attribute__((aligned(16))) float red[2][WAVES][NT][RH][64][4];
   constexpr int SW = WAVES < 4 ? WAVES : 4;
   __shared__ float sh_ps[SW][RH][64];
+  __shared__ uint16_t sh_patch[2][CW ? 256 : 1];                    // CW: the unit's escaped values (two unit parities)
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   ScaleRegs<RH> sc;
@@ -369,18 +493,33 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_pers_kernel(GemvArgs a, int u
   x_pointers<RH>(a, lane, xp, row_ok, xstep);
   const size_t unit_stride = (size_t)NT * KT * 512;                 // elements between consecutive units
   const bf16_t* wbase = a.Wp + (size_t)blockIdx.x * unit_stride + lane * 8;
+  uint16_t pnext = 0;                                               // CW: this thread's patch entry of the NEXT unit, in flight
+  auto patch_fetch = [&](int unit) {
+    if constexpr (CW) {
+      if (tid < 256 && unit < units) pnext = a.patch[(size_t)unit * 256 + tid];
+    }
+  };
 
-  bf16x8 wA[U][NT], wB[U][NT];
+  WFrag<CW> wA[U][NT], wB[U][NT];
   u32x4 xA[U][RH], xB[U][RH];
 #pragma unroll
   for (int u = 0; u < U; ++u)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) wA[u][nt] = wB[u][nt] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    for (int nt = 0; nt < NT; ++nt) {
+      if constexpr (CW) { wA[u][nt].r.c = u32x3{0u, 0u, 0u}; wB[u][nt].r = wA[u][nt].r; }
+      else wA[u][nt].v = wB[u][nt].v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
 
   // load cursor: step ls = (unit lj, k index li)
   int ls = 0, li = 0;
   const bf16_t* lw = wbase;                                         // weights of the load cursor's unit
-  auto wload = [&](bf16x8 (&dst)[U][NT], u32x4 (&xd)[U][RH]) {
+  size_t lblk = (size_t)blockIdx.x * NT * KT;                       // CW: first block of the load cursor's unit
+  uint32_t eA[U][NT], eB[U][NT];                                    // CW: the blocks' emin bytes (SGPRs), loaded with the weights
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) eA[u][nt] = eB[u][nt] = 0u;
+  auto wload = [&](WFrag<CW> (&dst)[U][NT], u32x4 (&xd)[U][RH], uint32_t (&ed)[U][NT]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
 #pragma unroll
@@ -388,18 +527,31 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_pers_kernel(GemvArgs a, int u
       if (ls < T) {                                                  // wave-uniform
         const int kt = w + li * WAVES;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          dst[u][nt] = __builtin_nontemporal_load((const bf16x8*)(lw + ((size_t)nt * KT + kt) * 512));
+        for (int nt = 0; nt < NT; ++nt) {
+          if constexpr (CW) {
+            const size_t blk = lblk + (size_t)nt * KT + kt;
+            dst[u][nt].r.c = __builtin_nontemporal_load((const u32x3*)(a.Wc + blk * 768 + lane * 12));
+            ed[u][nt] = cw_base_byte(cw_base_word(a.emin, blk), blk);
+          } else {
+            dst[u][nt].v = __builtin_nontemporal_load((const bf16x8*)(lw + ((size_t)nt * KT + kt) * 512));
+          }
+        }
 #pragma unroll
         for (int hf = 0; hf < RH; ++hf)
           if (row_ok[hf]) xd[u][hf] = *(const u32x4*)(xp[hf] + (size_t)kt * xstep);
         ++ls;
-        if (++li == nk) { li = 0; lw += (size_t)G * unit_stride; }
+        if (++li == nk) { li = 0; lw += (size_t)G * unit_stride; lblk += (size_t)G * NT * KT; }
       }
     }
   };
-  wload(wA, xA);
-  wload(wB, xB);
+  wload(wA, xA, eA);
+  wload(wB, xB, eB);
+  if constexpr (CW) {   // patch table of the first unit (the weight loads above are already in flight), the second one requested
+    patch_fetch(blockIdx.x);
+    if (tid < 256) sh_patch[0][tid] = pnext;
+    patch_fetch(blockIdx.x + G);
+    __syncthreads();
+  }
 
   f32x4 acc[NT][RH];
 #pragma unroll
@@ -407,15 +559,24 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_pers_kernel(GemvArgs a, int u
 #pragma unroll
     for (int hf = 0; hf < RH; ++hf) acc[nt][hf] = f32x4{0.f, 0.f, 0.f, 0.f};
   int cs = 0, ci = 0, cj = 0;                                       // compute cursor
-  auto compute = [&](bf16x8 (&src)[U][NT], u32x4 (&xs)[U][RH]) {
+  auto compute = [&](WFrag<CW> (&src)[U][NT], u32x4 (&xs)[U][RH], uint32_t (&es)[U][NT]) {
 #pragma unroll
     for (int u = 0; u < U; ++u)
       if (cs < T) {
+        bf16x8 wf[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          if constexpr (CW) {
+            wf[nt] = cw_decode(src[u][nt].r, es[u][nt], sh_patch[cj & 1]);
+          } else {
+            wf[nt] = src[u][nt].v;
+          }
+        }
 #pragma unroll
         for (int hf = 0; hf < RH; ++hf) {
           const bf16x8 xf = __builtin_bit_cast(bf16x8, xs[u][hf]);
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) acc[nt][hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(src[u][nt], xf, acc[nt][hf], 0, 0, 0);
+          for (int nt = 0; nt < NT; ++nt) acc[nt][hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf, acc[nt][hf], 0, 0, 0);
         }
         ++cs;
         if (++ci == nk) {                                            // unit cj complete: every wave passes here nu times
@@ -429,6 +590,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_pers_kernel(GemvArgs a, int u
               acc[nt][hf] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
           if (cj == 0) scale_park<SW, RH>(a, sc, sh_ps, w, lane);  // once, before the first epilogue of the workgroup
+          if constexpr (CW) {   // the next unit's patch table (requested one unit ago) into the other parity; request the one after
+            if (tid < 256) sh_patch[(cj + 1) & 1][tid] = pnext;
+            patch_fetch(blockIdx.x + (cj + 2) * G);
+          }
           __syncthreads();
           if (w == cj % WAVES) {
             const int unit = blockIdx.x + cj * G;
@@ -445,20 +610,27 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_pers_kernel(GemvArgs a, int u
       }
   };
   while (cs < T) {
-    compute(wA, xA);
-    wload(wA, xA);
-    compute(wB, xB);
-    wload(wB, xB);
+    compute(wA, xA, eA);
+    wload(wA, xA, eA);
+    compute(wB, xB, eB);
+    wload(wB, xB, eB);
   }
 }
 
-template <int NT, int EPI, int WAVES, int U, int RH>
-void go_pers_rh(const GemvArgs& a, int ntiles, int grid, hipStream_t s) {
+template <int NT, int EPI, int WAVES, int U, int RH, bool CW>
+void go_pers_cw(const GemvArgs& a, int ntiles, int grid, hipStream_t s) {
   if (a.ev_start)
-    hipExtLaunchKernelGGL((gemv_pers_kernel<NT, EPI, WAVES, U, RH>), dim3(grid), dim3(WAVES * 64), 0, s, (hipEvent_t)a.ev_start,
+    hipExtLaunchKernelGGL((gemv_pers_kernel<NT, EPI, WAVES, U, RH, CW>), dim3(grid), dim3(WAVES * 64), 0, s, (hipEvent_t)a.ev_start,
                           (hipEvent_t)a.ev_stop, 0, a, ntiles / NT);
   else
-    hipLaunchKernelGGL((gemv_pers_kernel<NT, EPI, WAVES, U, RH>), dim3(grid), dim3(WAVES * 64), 0, s, a, ntiles / NT);
+    hipLaunchKernelGGL((gemv_pers_kernel<NT, EPI, WAVES, U, RH, CW>), dim3(grid), dim3(WAVES * 64), 0, s, a, ntiles / NT);
+}
+template <int NT, int EPI, int WAVES, int U, int RH>
+void go_pers_rh(const GemvArgs& a, int ntiles, int grid, hipStream_t s) {
+  if constexpr (WAVES >= 4) {   // the compressed stream needs 256 threads for the patch table
+    if (a.Wc) return go_pers_cw<NT, EPI, WAVES, U, RH, true>(a, ntiles, grid, s);
+  }
+  go_pers_cw<NT, EPI, WAVES, U, RH, false>(a, ntiles, grid, s);
 }
 // more than 16 rows: the two-row-half kernels (same weights pass, two B fragments per weight fragment)
 template <int NT, int EPI, int WAVES, int U>
@@ -467,13 +639,20 @@ void go_pers(const GemvArgs& a, int ntiles, int grid, hipStream_t s) {
   else go_pers_rh<NT, EPI, WAVES, U, 1>(a, ntiles, grid, s);
 }
 
-template <int NT, int EPI, int WAVES, int U, int KMODE, int RH>
-void go_rh(const GemvArgs& a, int ntiles, hipStream_t s) {
+template <int NT, int EPI, int WAVES, int U, int KMODE, int RH, bool CW>
+void go_cw(const GemvArgs& a, int ntiles, hipStream_t s) {
   if (a.ev_start)
-    hipExtLaunchKernelGGL((gemv_kernel<NT, EPI, WAVES, U, KMODE, RH>), dim3(ntiles / NT), dim3(WAVES * 64), 0, s, (hipEvent_t)a.ev_start,
+    hipExtLaunchKernelGGL((gemv_kernel<NT, EPI, WAVES, U, KMODE, RH, CW>), dim3(ntiles / NT), dim3(WAVES * 64), 0, s, (hipEvent_t)a.ev_start,
                           (hipEvent_t)a.ev_stop, 0, a);
   else
-    hipLaunchKernelGGL((gemv_kernel<NT, EPI, WAVES, U, KMODE, RH>), dim3(ntiles / NT), dim3(WAVES * 64), 0, s, a);
+    hipLaunchKernelGGL((gemv_kernel<NT, EPI, WAVES, U, KMODE, RH, CW>), dim3(ntiles / NT), dim3(WAVES * 64), 0, s, a);
+}
+template <int NT, int EPI, int WAVES, int U, int KMODE, int RH>
+void go_rh(const GemvArgs& a, int ntiles, hipStream_t s) {
+  if constexpr (WAVES >= 4) {   // the compressed stream needs 256 threads for the patch table
+    if (a.Wc) return go_cw<NT, EPI, WAVES, U, KMODE, RH, true>(a, ntiles, s);
+  }
+  go_cw<NT, EPI, WAVES, U, KMODE, RH, false>(a, ntiles, s);
 }
 template <int NT, int EPI, int WAVES, int U, int KMODE>
 void go(const GemvArgs& a, int ntiles, hipStream_t s) {
@@ -487,7 +666,8 @@ void go(const GemvArgs& a, int ntiles, hipStream_t s) {
 //   qkv + rotary (256 units of 3 tiles: a rotary pair  one unit per workgroup, K split 8 ways, two k-tiles per buffer
 //   of q or k + one v tile)                            (384 two-tile units on 4 waves: 18.8 us; 256 balanced units: 18.1 us)
 //   gate/up (688), lm_head (1000)                      persistent: ceil(units / 256) units per workgroup, 12 / 8 waves
-//                                                      (30.8 -> 29.4 us, 41.4 -> 40.3 us)
+//                                                      (30.8 -> 29.4 us, 41.4 -> 40.3 us); with the compressed weight stream
+//                                                      gate/up runs 16 waves (23.8 us) and lm_head two workgroups per CU (32.3 us)
 // Tried and removed: RMSNorm in the prologue of the persistent kernel (row scales from the partials, activation image in
 // LDS, rows <= 8; bit-identical to the separate launch). Kernel time +3.2 us (gate/up) / +2.8 us (qkv) against the
 // 4.7 us launch it replaces, and end to end 3.32 vs 3.29 ms/token: the small launch overlaps the neighbours' ramp.
@@ -498,16 +678,23 @@ hipError_t pick_default(const GemvArgs& a, int ntiles, hipStream_t s) {
   const int grid = (units + per - 1) / per;
   // The K split (number of waves) depends on the SHAPE only, never on the row count: the fp32 summation order, and with
   // it every output bit of a row, is the same alone and inside any batch.
+  // Compressed weights (a.Wc): the same K split as the bf16 stream (so the same bits), but 768-B blocks need more blocks in
+  // flight for the same bytes in flight: two k-tiles per buffer on the short-K one-unit kernels, two workgroups per CU on lm_head.
   if (units <= 256 || KT < 12) {
     if (units <= 256 && EPI == EPI_ROPE_KV && KT >= 16) go<NT, EPI, 8, 2, 1>(a, ntiles, s);   // 3-tile units: 18.1 vs 18.4 us
+    else if (units <= 256 && a.Wc && KT >= 64 && KT <= 128) go<NT, EPI, 16, 2, 1>(a, ntiles, s);   // o_proj compressed: 7.1 vs 7.4 us
     else if (units <= 256) go<NT, EPI, 16, 1, 1>(a, ntiles, s);
     else go<NT, EPI, 4, 2, 1>(a, ntiles, s);
   } else if constexpr (EPI == EPI_ROPE_KV) {
     go_pers<NT, EPI, 4, 1>(a, ntiles, units, s);
   } else if constexpr (EPI == EPI_SWIGLU) {
-    go_pers<NT, EPI, 12, 1>(a, ntiles, grid, s);
+    // 16 waves: the compressed stream is partly bound by the decode's vector work (12 waves: 24.7 us, 16: 23.8; in the engine
+    // 28.1 -> 26.6 us); the bf16 fallback keeps the same K split (so the same bits) and pays 2 us for it (31.8 vs 29.8 us)
+    if (a.Wc) go_pers<NT, EPI, 16, 2>(a, ntiles, grid, s);
+    else go_pers<NT, EPI, 16, 1>(a, ntiles, grid, s);
   } else {
-    go_pers<NT, EPI, 8, 1>(a, ntiles, grid, s);
+    const int per2 = (units + 511) / 512;
+    go_pers<NT, EPI, 8, 1>(a, ntiles, a.Wc ? (units + per2 - 1) / per2 : grid, s);   // lm_head compressed: grid 500: 32.3 vs 39.4 us
   }
   return hipGetLastError();
 }
@@ -544,7 +731,8 @@ hipError_t pick(const GemvArgs& a, int ntiles, int variant, hipStream_t s) {
 // variant 0 = tuned default; others (GEMV_ALL_VARIANTS builds only) select (WAVES, U, KMODE) for tools/decode_bench
 hipError_t launch_gemv_ex(const GemvArgs& a, int epi, int variant, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
-  if (a.M > 32 || (a.K & 31) || (a.N & 15)) return hipErrorInvalidValue;
+  if (a.M > 32 || (a.K & 31) || (a.N & 15) || (!a.Wp && !a.Wc)) return hipErrorInvalidValue;
+  if (a.Wc && (!a.emin || !a.patch)) return hipErrorInvalidValue;
   const int ntiles = a.N / 16;
   switch (epi) {
     case EPI_NONE: return pick<1, EPI_NONE>(a, ntiles, variant, s);
@@ -596,4 +784,24 @@ hipError_t launch_gemv(const GemmArgs& g, int epi, hipStream_t s) {
   a.X = g.X; a.ldx = g.ldx; a.Wp = g.Wp; a.bias = g.bias; a.R = g.R; a.ldr = g.ldr; a.C = g.C; a.ldc = g.ldc;
   a.M = g.M; a.N = g.N; a.K = g.K; a.Nvalid = g.Nvalid;
   return launch_gemv_ex(a, epi, 0, s);
+}
+
+// Lossless 12-bit compression of a packed weight matrix for the decode GEMVs (format: top of this file). nt_unit must be the
+// NT the GEMV of this shape / epilogue runs with (gemv_unit_tiles). cnt: n_units ints (zeroed here); *overflow_dev: int flag.
+int gemv_unit_tiles(int epi, int N) {
+  if (epi == EPI_SWIGLU) return 2;
+  if (epi == EPI_ROPE_KV) return 3;
+  if (epi == EPI_F32) return ((N / 16) % 2 == 0) ? 2 : 1;
+  return 1;
+}
+hipError_t launch_compress_weight(const bf16_t* Wp, int N, int K, int nt_unit, uint8_t* Wc, uint8_t* emin, uint16_t* patch, int* cnt,
+                                  int* overflow_dev, hipStream_t s) {
+  if ((N & 15) || (K & 31) || nt_unit < 1 || (N / 16) % nt_unit) return hipErrorInvalidValue;
+  const int ntiles = N / 16, KT = K / 32, units = ntiles / nt_unit;
+  hipError_t err = hipMemsetAsync(cnt, 0, (size_t)units * 4, s);
+  if (err != hipSuccess) return err;
+  err = hipMemsetAsync(patch, 0, (size_t)units * 256 * 2, s);
+  if (err != hipSuccess) return err;
+  hipLaunchKernelGGL(cw_compress_kernel, dim3((unsigned)((size_t)ntiles * KT)), dim3(64), 0, s, Wp, KT, nt_unit, Wc, emin, patch, cnt, overflow_dev);
+  return hipGetLastError();
 }

@@ -58,11 +58,21 @@ struct GemvArgs {
   const float* ssq_in; int n_part; int norm_d; float norm_eps;
   // EPI_RESIDUAL: when non-null the new hidden rows are ALSO written in the fragment-ordered layout (input of the next projection)
   bf16_t* C_xf;
+  // Losslessly compressed weights (gemv.hip "12-bit blocks"): when Wc is non-null the kernel streams Wc / emin instead of Wp.
+  // Wc: per 1-KiB fragment block 768 B (lane l: 12 B = its 8 elements at 12 bits: sign, 4-bit exponent offset, 7-bit mantissa);
+  // emin[block]: bits 0-6 = (smallest coded exponent field) / 2, bit 7 = the block has escaped elements;
+  // patch / patch_off: escaped elements' true bf16 bits, patch_off[unit] .. patch_off[unit + 1] (<= 256 per unit)
+  const uint8_t* Wc = nullptr; const uint8_t* emin = nullptr; const uint16_t* patch = nullptr; const int* patch_off = nullptr;
   // optional (host side only): HIP events that bracket exactly this kernel's execution (hipExtLaunchKernelGGL start /
   // stop events = the dispatch's own timestamps, what rocprofv3's kernel trace reports), for orc_profile_read
   void* ev_start; void* ev_stop;
 };
 hipError_t launch_gemv_ex(const GemvArgs& a, int epi, int variant, hipStream_t s);
+// lossless 12-bit compression of a packed matrix for the decode GEMVs (gemv.hip): Wc N*K*3/2 bytes, emin N/16*K/32 bytes (+3 pad),
+// patch (N/16/nt_unit)*256 uint16, cnt N/16/nt_unit ints; *overflow_dev is set when a unit has more than 256 escapes
+int gemv_unit_tiles(int epi, int N);
+hipError_t launch_compress_weight(const bf16_t* Wp, int N, int K, int nt_unit, uint8_t* Wc, uint8_t* emin, uint16_t* patch, int* cnt,
+                                  int* overflow_dev, hipStream_t s);
 // colscale (bf16 [K], may be null): Wp holds bf16(W[n][k] * colscale[k])
 hipError_t launch_pack_weight(const bf16_t* W, int Nsrc, int K, const int* rowmap, bf16_t* Wp, int Np, int Kp,
                               hipStream_t s, const bf16_t* colscale = nullptr);

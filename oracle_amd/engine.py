@@ -223,18 +223,23 @@ class Engine:
     def kv_bytes_per_key(self):
         return int(self.lib.orc_kv_bytes_per_key(self._h))
 
+    def decode_stream_bytes(self, which=0):
+        """Physical weight bytes streamed per decode step (which=0) or per gate/up launch (which=1): 12-bit copies where active."""
+        return int(self.lib.orc_decode_stream_bytes(self._h, which))
+
 
 # ---------------------------------------------------------------------- single-kernel hooks (tests, profiling)
 def test_gemm(x, w, bias=None, residual=None, epilogue='none', use_gemv=False, kernel=None):
     """kernel: None (automatic), 'tile128' (register-staged 128^2), 'dma256' / 'dma128' (LDS-DMA, BM x 256 tiles of one
-    height), 'mix<n>' (LDS-DMA, n 256-row m-tiles + 128-row tiles for the remaining rows in one launch)."""
+    height), 'mix<n>' (LDS-DMA, n 256-row m-tiles + 128-row tiles for the remaining rows in one launch).
+    use_gemv='cw': the decode GEMV on the lossless 12-bit copy of w (must equal use_gemv=True bit for bit)."""
     l = _lib.lib()
     m, k = x.shape
     n = w.shape[0]
     nout = n // 2 if epilogue == 'swiglu' else n
     out = torch.empty(m, nout, dtype=torch.float32 if epilogue == 'f32' else torch.bfloat16, device=x.device)
     _lib.check(l.orc_test_gemm(_ptr(x), m, k, _ptr(w), n, _ptr(bias), _ptr(residual), EPI[epilogue],
-                               1 if use_gemv else (100 + int(kernel[3:]) if isinstance(kernel, str) and kernel.startswith('mix') else {None: 0, 'tile128': 2, 'dma256': 3, 'dma128': 4}[kernel]),
+                               5 if use_gemv == 'cw' else 1 if use_gemv else (100 + int(kernel[3:]) if isinstance(kernel, str) and kernel.startswith('mix') else {None: 0, 'tile128': 2, 'dma256': 3, 'dma128': 4}[kernel]),
                                _ptr(out), _stream()), 'orc_test_gemm')
     return out
 

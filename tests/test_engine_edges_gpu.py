@@ -169,3 +169,34 @@ def test_batch_of_32_ragged_rows_matches_oracle():
     n = min(half.shape[1], out.shape[1])
     assert torch.equal(half[:, L:n], out[16:, L:n])
     eng.close()
+
+
+def test_compressed_decode_weights_give_the_same_bits(monkeypatch):
+    """The engine streams lossless 12-bit copies of the decode weights (gemv.hip; default) -- against the same engine with
+    ORC_DECODE_WEIGHTS=plain (bf16 stream): prefill logits, the logits of 6 decode steps and the free-running tokens of a
+    ragged batch are equal bit for bit."""
+    from oracle_amd.dims import TINY
+    from oracle_amd.engine import Engine
+    from oracle_amd.llava.model.language_model.llava_llama import LlavaConfig, LlavaLlamaForCausalLM
+    from oracle_amd.synth import install_chain, synth_images, synth_state
+    st = install_chain(synth_state(TINY, seed=0), TINY)
+    ids = _prompts(9)
+    imgs = synth_images(9, 3, TINY, seed=91)
+    got = {}
+    for mode in ('plain', 'cw12'):
+        monkeypatch.setenv('ORC_DECODE_WEIGHTS', mode)
+        eng = Engine(TINY, max_batch=9, max_seq=700, max_images=27, max_new_tokens=40)
+        eng.load_state(st)
+        model = LlavaLlamaForCausalLM(LlavaConfig(TINY, tokenizer_padding_side='left'), eng)
+        toks = model.generate(ids.cuda(), images=imgs.cuda(), do_sample=False, use_cache=True, max_new_tokens=30).cpu()
+        mask = ids != 0
+        pos = mask.long().cumsum(-1) - 1
+        pos.masked_fill_(~mask, 1)
+        logits = [model(input_ids=ids.cuda(), attention_mask=mask.cuda(), position_ids=pos.cuda(), images=imgs.cuda(),
+                        use_cache=True).logits[:, -1].float().cpu()]
+        for step in range(6):
+            logits.append(eng.decode_step(logits[-1].argmax(-1).cuda(), want_logits=True).float().cpu())
+        got[mode] = (toks, torch.stack(logits))
+        eng.close()
+    assert torch.equal(got['plain'][0], got['cw12'][0])
+    assert torch.equal(got['plain'][1].view(torch.int32), got['cw12'][1].view(torch.int32))

@@ -239,3 +239,54 @@ def test_decode_gemv_at_llama7b_shapes(epi, N, K, M):
     if M > 16:       # rows of the second MFMA B tile: the same bits as when they run alone as rows 0..M-17
         tail = E.test_gemm(x[16:].to(d), w.to(d), None, None if res is None else res[16:].to(d), epi, use_gemv=True).cpu()
         assert torch.equal(tail, out[16:])
+
+
+def _nasty_weights(N, K, seed):
+    """Gaussian weights with everything the 12-bit block format has to escape or cover, at rates that stay under the 256 patch
+    entries of a GEMV unit (up to 176k elements): exact zeros (+0 and -0), values 2^-20 and 2^-30 times the scale (below a
+    block's 16 binades), bf16 denormals, three huge outliers (each lifts its block's base and pushes ~50 ordinary values of that
+    block out of range), an all-zero 16-row tile (padding), a dense run of zeros inside one block."""
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn(N, K, generator=g) * 0.02
+    r = torch.rand(N, K, generator=g)
+    w[r < 1e-4] = 0.0
+    w[(r >= 1e-3) & (r < 1.05e-3)] = -0.0
+    w[(r >= 2e-3) & (r < 2.1e-3)] *= 2.0 ** -20
+    w[(r >= 3e-3) & (r < 3.05e-3)] *= 2.0 ** -30
+    w[(r >= 4e-3) & (r < 4.02e-3)] = 1e-40                      # bf16 denormal
+    for n, k in ((3, 7), (N // 3, K // 2 + 1), (N - 2, K - 5)):
+        w[n, k] = 90.0
+    w[32:48] = 0.0
+    w[5, 64:96] = 0.0
+    return w.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize('M', [1, 8, 32])
+@pytest.mark.parametrize('epi,N,K', [('swiglu', 22016, 4096), ('f32', 32000, 4096), ('residual', 4096, 11008), ('residual', 4096, 4096),
+                                     ('none', 12288, 4096), ('swiglu', 2816, 512), ('residual', 512, 1408), ('f32', 32000, 512),
+                                     ('none', 1536, 512)])
+def test_compressed_weight_stream_is_bit_exact(epi, N, K, M):
+    """The decode GEMVs on the lossless 12-bit copy of the weights (768 B per 1-KiB fragment block, gemv.hip) against the same
+    kernels on the bf16 weights: every output bit equal, for plain Gaussian weights and for weights full of escapes (zeros,
+    tiny values, denormals, outliers), at the 7B shapes and the TINY ones, 1 / 8 / 32 rows."""
+    from oracle_amd import engine as E
+    d = _dev()
+    x = _rand((M, K), 51).to(d)
+    res = _rand((M, N), 53).to(d) if epi == 'residual' else None
+    for w in (_rand((N, K), 52, 0.02), _nasty_weights(N, K, 54)):
+        w = w.to(d)
+        plain = E.test_gemm(x, w, None, res, epi, use_gemv=True)
+        packed = E.test_gemm(x, w, None, res, epi, use_gemv='cw')
+        assert torch.equal(plain.view(torch.int32 if epi == 'f32' else torch.int16), packed.view(torch.int32 if epi == 'f32' else torch.int16))
+
+
+def test_compressed_weight_stream_refuses_more_than_256_escapes_per_unit():
+    """A unit (16 rows x K of a one-tile kernel) whose blocks need more than 256 patch entries cannot be compressed: the hook
+    reports it (the engine then keeps that matrix in bf16, engine.hip compress_for_decode)."""
+    from oracle_amd import engine as E
+    d = _dev()
+    w = (torch.randn(256, 4096) * 0.02).to(torch.bfloat16)
+    w[:16, ::4] = (torch.randn(16, 1024) * 1e-12).to(torch.bfloat16)      # 1024 far-out-of-range values in unit 0
+    x = _rand((4, 4096), 3).to(d)
+    with pytest.raises(RuntimeError, match='not compressible'):
+        E.test_gemm(x, w.to(d), None, None, 'none', use_gemv='cw')

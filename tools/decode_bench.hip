@@ -150,6 +150,70 @@ int main(int argc, char** argv) {
       else printf("%s W%-2d U%d    : %7.2f us  %7.1f GB/s\n", sh.name, 1 << (vi / 3), variant == 15 ? 1 : 2 << (vi % 3), us, wbytes / us * 1e-3);
     }
   }
+  // ---- compressed weight stream (12-bit blocks, gemv.hip CW kernels): timing on arbitrary compressed bytes, no escapes
+  if (getenv("CW_EXP")) {
+    uint8_t* emin;
+    uint16_t* patch;
+    CK(hipMalloc((void**)&emin, (size_t)8 << 20));
+    CK(hipMemset(emin, 56, (size_t)8 << 20));          // emin = 112, no escape flag
+    CK(hipMalloc((void**)&patch, (size_t)4096 * 256 * 2));
+    CK(hipMemset(patch, 0, (size_t)4096 * 256 * 2));
+    for (const Shape& sh : shapes) {
+      const size_t wbytes = (size_t)sh.N * sh.K * 2, cbytes = wbytes / 4 * 3;
+      GemvArgs a = {};
+      a.X = X; a.ldx = sh.K; a.bias = nullptr; a.R = R; a.ldr = sh.N; a.C = Y;
+      a.ldc = sh.epi == EPI_SWIGLU ? sh.N / 2 : (sh.epi == EPI_ROPE_KV ? d : sh.N);
+      a.M = M; a.N = sh.N; a.K = sh.K; a.Nvalid = sh.epi == EPI_SWIGLU ? sh.N / 2 : sh.N;
+      a.H = H; a.kbeg = ints + 16; a.cur_len = ints; a.cos_tab = cosb; a.sin_tab = sinb;
+      a.maxpos = 4096; a.Kc = Kc; a.Vc = Vc; a.c_bs = (long)H * Tmax * 128; a.c_hs = (long)Tmax * 128;
+      a.ssq_out = ssq; a.x_xf = 1; a.c_xf = 1;
+      a.emin = emin; a.patch = patch;
+      for (int cw = 0; cw < 2; ++cw) {
+        hipError_t err = hipSuccess;
+        float us = time_it([&](int i) {
+          const size_t off = (((size_t)i * wbytes) % (pool_bytes - wbytes)) & ~(size_t)1023;
+          a.Wp = (const bf16_t*)((char*)pool + off);
+          a.Wc = cw ? (const uint8_t*)pool + off : nullptr;
+          hipError_t e = launch_gemv_ex(a, sh.epi, 0, s);
+          if (e != hipSuccess) err = e;
+        });
+        if (err != hipSuccess) { printf("%s cw%d : %s\n", sh.name, cw, hipGetErrorString(err)); (void)hipGetLastError(); continue; }
+        printf("%s %s : %7.2f us  (%5.1f MB streamed, %7.1f GB/s physical)\n", sh.name, cw ? "compressed" : "plain     ", us,
+               (cw ? cbytes : wbytes) * 1e-6, (cw ? cbytes : wbytes) / us * 1e-3);
+      }
+      for (int variant : {7, 8, 10, 11, 13, 14, 15}) {   // one unit per workgroup: W in {4, 8, 16}, U in {2, 4} (15: W16 U1)
+        hipError_t err = hipSuccess;
+        float us = time_it([&](int i) {
+          const size_t off = (((size_t)i * wbytes) % (pool_bytes - wbytes)) & ~(size_t)1023;
+          a.Wp = (const bf16_t*)((char*)pool + off);
+          a.Wc = (const uint8_t*)pool + off;
+          hipError_t e = launch_gemv_ex(a, sh.epi, variant, s);
+          if (e != hipSuccess) err = e;
+        });
+        if (err != hipSuccess) { (void)hipGetLastError(); continue; }
+        const int vi = variant - 1;
+        printf("%s compressed W%-2d U%d : %7.2f us   %7.1f GB/s physical\n", sh.name, 1 << (vi / 3), variant == 15 ? 1 : 2 << (vi % 3), us, cbytes / us * 1e-3);
+      }
+      // persistent sweep on the compressed stream
+      const int units = sh.N / 16 / (sh.epi == EPI_RESIDUAL ? 1 : (sh.epi == EPI_ROPE_KV ? 3 : 2));
+      for (int waves : {8, 12, 16})
+        for (int u : {1, 2})
+          for (int div : {1, 2, 3, 4}) {
+            const int grid = (units + div - 1) / div;
+            if (grid > 512 || grid < 128) continue;
+            hipError_t err = hipSuccess;
+            float us = time_it([&](int i) {
+              const size_t off = (((size_t)i * wbytes) % (pool_bytes - wbytes)) & ~(size_t)1023;
+              a.Wp = (const bf16_t*)((char*)pool + off);
+              a.Wc = (const uint8_t*)pool + off;
+              hipError_t e = launch_gemv_pers(a, sh.epi, waves, u, grid, s);
+              if (e != hipSuccess) err = e;
+            });
+            if (err != hipSuccess) { (void)hipGetLastError(); continue; }
+            printf("%s compressed pers W%-2d U%d grid %4d : %7.2f us  %7.1f GB/s physical\n", sh.name, waves, u, grid, us, cbytes / us * 1e-3);
+          }
+    }
+  }
   // ---- persistent GEMV: (waves, U, grid) sweep, checked against the default kernel's output
   if (getenv("PERS_EXP")) {
     for (const Shape& sh : shapes) {
