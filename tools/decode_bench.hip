@@ -45,7 +45,21 @@ __global__ void fill_kernel(uint16_t* p, size_t n, uint32_t seed) {
   }
 }
 
+// N(0, 0.02^2) bf16 values (Box-Muller on a hash): the escape statistics of real weights for the compressed-stream timing
+__global__ void gauss_kernel(uint16_t* p, size_t n, uint32_t seed) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    uint32_t h = (uint32_t)i * 2654435761u + seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+    uint32_t g = h * 747796405u + 2891336453u; g ^= g >> 15; g *= 2246822519u; g ^= g >> 13;
+    const float u1 = ((h >> 8) + 1) * (1.0f / 16777217.0f), u2 = (g >> 8) * (1.0f / 16777216.0f);
+    const float z = sqrtf(-2.0f * logf(u1)) * cosf(6.2831853f * u2) * 0.02f;
+    p[i] = (uint16_t)(__float_as_uint(z) >> 16);
+  }
+}
+
 struct Shape { const char* name; int N, K, epi; };
+int gemv_unit_tiles(int epi, int N);
+hipError_t launch_compress_weight(const bf16_t* Wp, int N, int K, int nt_unit, uint8_t* Wc, uint8_t* emin, uint16_t* patch, int* cnt,
+                                  int* overflow_dev, hipStream_t s);
 hipError_t launch_gemv_pers(const GemvArgs& a, int epi, int waves, int u, int grid, hipStream_t s);
 
 int main(int argc, char** argv) {
@@ -193,6 +207,32 @@ int main(int argc, char** argv) {
         if (err != hipSuccess) { (void)hipGetLastError(); continue; }
         const int vi = variant - 1;
         printf("%s compressed W%-2d U%d : %7.2f us   %7.1f GB/s physical\n", sh.name, 1 << (vi / 3), variant == 15 ? 1 : 2 << (vi % 3), us, cbytes / us * 1e-3);
+      }
+      {   // the same launch on REAL compressed data: Gaussian weights through the compressor (escapes on ~5 % of the blocks)
+        bf16_t* gw;
+        uint8_t *gc, *ge;
+        uint16_t* gp;
+        int* cnt;
+        const int ntu = gemv_unit_tiles(sh.epi, sh.N), un = sh.N / 16 / ntu;
+        const size_t nblk = (size_t)sh.N / 16 * sh.K / 32;
+        CK(hipMalloc((void**)&gw, wbytes)); CK(hipMalloc((void**)&gc, nblk * 768)); CK(hipMalloc((void**)&ge, nblk + 8));
+        CK(hipMalloc((void**)&gp, (size_t)un * 512)); CK(hipMalloc((void**)&cnt, (size_t)(un + 1) * 4));
+        hipLaunchKernelGGL(gauss_kernel, dim3(4096), dim3(256), 0, 0, gw, wbytes / 2, 99u);
+        CK(hipMemset(cnt + un, 0, 4));
+        CK(launch_compress_weight(gw, sh.N, sh.K, ntu, gc, ge, gp, cnt, cnt + un, 0));
+        std::vector<int> hc(un + 1);
+        CK(hipMemcpy(hc.data(), cnt, (size_t)(un + 1) * 4, hipMemcpyDeviceToHost));
+        long esc = 0; int mx = 0;
+        for (int i = 0; i < un; ++i) { esc += hc[i]; mx = hc[i] > mx ? hc[i] : mx; }
+        GemvArgs b = a;
+        b.Wp = nullptr; b.Wc = gc; b.emin = ge; b.patch = gp;
+        hipError_t err = hipSuccess;
+        float us = time_it([&](int i) { hipError_t e = launch_gemv_ex(b, sh.epi, 0, s); if (e != hipSuccess) err = e; });   // same weights every launch: partly cache-resident
+        b.emin = emin;   // same bytes, no block flagged
+        float us0 = time_it([&](int i) { hipError_t e = launch_gemv_ex(b, sh.epi, 0, s); if (e != hipSuccess) err = e; });
+        printf("%s compressed Gaussian weights: %ld escapes (%.2e per element, max %d per unit, overflow %d): %7.2f us; same bytes with no block flagged: %7.2f us%s\n",
+               sh.name, esc, (double)esc / ((double)sh.N * sh.K), mx, hc[un], us, us0, err != hipSuccess ? "  LAUNCH ERROR" : "");
+        CK(hipFree(gw)); CK(hipFree(gc)); CK(hipFree(ge)); CK(hipFree(gp)); CK(hipFree(cnt));
       }
       // persistent sweep on the compressed stream
       const int units = sh.N / 16 / (sh.epi == EPI_RESIDUAL ? 1 : (sh.epi == EPI_ROPE_KV ? 3 : 2));
