@@ -56,6 +56,9 @@ __global__ void gauss_kernel(uint16_t* p, size_t n, uint32_t seed) {
   }
 }
 
+__global__ void clear_flags_kernel(uint8_t* e, size_t nblk) {   // timing experiment: same bases, no block flagged
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nblk; i += (size_t)gridDim.x * blockDim.x) e[2 * i] &= 0x7f;
+}
 struct Shape { const char* name; int N, K, epi; };
 int gemv_unit_tiles(int epi, int N);
 hipError_t launch_compress_weight(const bf16_t* Wp, int N, int K, int nt_unit, uint8_t* Wc, uint8_t* emin, uint16_t* patch, int* cnt,
@@ -195,7 +198,8 @@ int main(int argc, char** argv) {
         printf("%s %s : %7.2f us  (%5.1f MB streamed, %7.1f GB/s physical)\n", sh.name, cw ? "compressed" : "plain     ", us,
                (cw ? cbytes : wbytes) * 1e-6, (cw ? cbytes : wbytes) / us * 1e-3);
       }
-      for (int variant : {7, 8, 10, 11, 13, 14, 15}) {   // one unit per workgroup: W in {4, 8, 16}, U in {2, 4} (15: W16 U1)
+      for (int variant : {7, 8, 10, 11, 13, 14, 15, 30, 31, 33, 34, 35}) {   // one unit per workgroup: W in {4, 8, 16}, U in {2, 4} (15: W16 U1); 20 + v: two-tile units
+        if (variant >= 20 && sh.epi != EPI_RESIDUAL) continue;
         hipError_t err = hipSuccess;
         float us = time_it([&](int i) {
           const size_t off = (((size_t)i * wbytes) % (pool_bytes - wbytes)) & ~(size_t)1023;
@@ -205,8 +209,8 @@ int main(int argc, char** argv) {
           if (e != hipSuccess) err = e;
         });
         if (err != hipSuccess) { (void)hipGetLastError(); continue; }
-        const int vi = variant - 1;
-        printf("%s compressed W%-2d U%d : %7.2f us   %7.1f GB/s physical\n", sh.name, 1 << (vi / 3), variant == 15 ? 1 : 2 << (vi % 3), us, cbytes / us * 1e-3);
+        const int vi = variant % 20 - 1;
+        printf("%s compressed %sW%-2d U%d : %7.2f us   %7.1f GB/s physical\n", sh.name, variant >= 20 ? "NT2 " : "", 1 << (vi / 3), variant % 20 == 15 ? 1 : 2 << (vi % 3), us, cbytes / us * 1e-3);
       }
       {   // the same launch on REAL compressed data: Gaussian weights through the compressor (escapes on ~5 % of the blocks)
         bf16_t* gw;
@@ -215,7 +219,7 @@ int main(int argc, char** argv) {
         int* cnt;
         const int ntu = gemv_unit_tiles(sh.epi, sh.N), un = sh.N / 16 / ntu;
         const size_t nblk = (size_t)sh.N / 16 * sh.K / 32;
-        CK(hipMalloc((void**)&gw, wbytes)); CK(hipMalloc((void**)&gc, nblk * 768)); CK(hipMalloc((void**)&ge, nblk + 8));
+        CK(hipMalloc((void**)&gw, wbytes)); CK(hipMalloc((void**)&gc, nblk * 768)); CK(hipMalloc((void**)&ge, 2 * nblk + 8));
         CK(hipMalloc((void**)&gp, (size_t)un * 512)); CK(hipMalloc((void**)&cnt, (size_t)(un + 1) * 4));
         hipLaunchKernelGGL(gauss_kernel, dim3(4096), dim3(256), 0, 0, gw, wbytes / 2, 99u);
         CK(hipMemset(cnt + un, 0, 4));
@@ -228,7 +232,7 @@ int main(int argc, char** argv) {
         b.Wp = nullptr; b.Wc = gc; b.emin = ge; b.patch = gp;
         hipError_t err = hipSuccess;
         float us = time_it([&](int i) { hipError_t e = launch_gemv_ex(b, sh.epi, 0, s); if (e != hipSuccess) err = e; });   // same weights every launch: partly cache-resident
-        b.emin = emin;   // same bytes, no block flagged
+        hipLaunchKernelGGL(clear_flags_kernel, dim3(1024), dim3(256), 0, 0, ge, nblk);   // same bytes and bases, no block flagged
         float us0 = time_it([&](int i) { hipError_t e = launch_gemv_ex(b, sh.epi, 0, s); if (e != hipSuccess) err = e; });
         printf("%s compressed Gaussian weights: %ld escapes (%.2e per element, max %d per unit, overflow %d): %7.2f us; same bytes with no block flagged: %7.2f us%s\n",
                sh.name, esc, (double)esc / ((double)sh.N * sh.K), mx, hc[un], us, us0, err != hipSuccess ? "  LAUNCH ERROR" : "");
