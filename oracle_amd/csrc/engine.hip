@@ -264,7 +264,7 @@ int compress_for_decode(orc_engine* e, Packed* W, int epi, bool drop_plain) {
   uint16_t* patch = nullptr;
   int* cnt = nullptr;
   ORCCHK(e->alloc((void**)&wc, nblk * 768));
-  ORCCHK(e->alloc((void**)&em, (2 * nblk + 7) & ~(size_t)3));
+  ORCCHK(e->alloc((void**)&em, (nblk + 7) & ~(size_t)3));
   ORCCHK(e->alloc((void**)&patch, (size_t)units * 256 * 2));
   HIPCHK(hipMalloc((void**)&cnt, (size_t)(units + 1) * 4));
   HIPCHK(hipMemset(cnt + units, 0, 4));
@@ -1030,7 +1030,7 @@ extern "C" int64_t orc_decode_weight_bytes(orc_engine* e) {
 }
 static int64_t stream_bytes(const Packed& W) {
   const int64_t nk = (int64_t)W.N * W.K;
-  return W.wc ? nk * 3 / 2 + nk / 256 : nk * 2;
+  return W.wc ? nk * 3 / 2 + nk / 512 : nk * 2;
 }
 extern "C" int64_t orc_decode_stream_bytes(orc_engine* e, int which) {
   if (!e || !e->finalized || e->llama.empty()) return 0;
@@ -1075,7 +1075,7 @@ extern "C" int orc_test_gemm(const void* x, int M, int K, const void* w, int N, 
     uint16_t* patch;
     int* cnt;
     HIPCHK(hipMalloc((void**)&wc, nblk * 768));
-    HIPCHK(hipMalloc((void**)&em, (2 * nblk + 7) & ~(size_t)3));
+    HIPCHK(hipMalloc((void**)&em, (nblk + 7) & ~(size_t)3));
     HIPCHK(hipMalloc((void**)&patch, (size_t)units * 256 * 2));
     HIPCHK(hipMalloc((void**)&cnt, (size_t)(units + 1) * 4));
     HIPCHK(hipMemsetAsync(cnt + units, 0, 4, s));

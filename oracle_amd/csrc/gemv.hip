@@ -32,12 +32,12 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 // of an element (sign, exponent bits 7..1) is stored as 4 bits -- sign and a 3-bit offset d from the block's base eh -- and the
 // low byte (exponent bit 0, mantissa) as it is, so a block is 768 B instead of 1 KiB and the decode GEMVs -- HBM-bound on the
 // weight stream -- move 25 % fewer bytes. The decode is exact (bit-for-bit the original bf16): a block covers the 16 binades
-// [2 eh, 2 eh + 15]; elements outside (zeros / tiny values under a large block maximum: ~1e-4 of Gaussian weights, ~4 % of the
-// blocks) are "escaped": the block is flagged and gives up its lowest exponent code as the marker. An escaped element keeps
-// its sign and mantissa in place, and the block carries ONE second exponent `elow` for all of them (side array, second byte):
-// one tiny value, or any number of zeros / denormals, cost ~25 more vector ops in that block and nothing else. Only a block
-// whose escaped elements have DIFFERENT exponents (~0.1 % of Gaussian blocks) sets elow = 0xff and stores, instead of sign
-// and mantissa, an 8-bit index into the unit's patch table of true values (256 entries per GEMV unit, in LDS).
+// [2 eh, 2 eh + 15]; elements outside (zeros / tiny values under a large block maximum: ~8e-5 of Gaussian weights, ~4 % of the
+// blocks) are "escaped": the block is flagged, gives up its lowest exponent code as the marker, and an element with that code
+// carries in its sign and mantissa fields an 8-bit index into the unit's patch table of true values (256 entries per GEMV
+// unit, in LDS). (Tried: a second per-block exponent for the escaped elements, so that only blocks with mixed out-of-range
+// exponents need the table -- 10x fewer lookups, but the second side byte and the longer decode made the COMMON path slower:
+// gate/up 24.7 -> 25.9 us on Gaussian weights. Removed.)
 // Lane layout (12 B): L0, L1 = low bytes of elements 0-3, 4-7; H = the eight 4-bit fields, element k < 4 in nibble 2k,
 // element 4 + k in nibble 2k + 1. ~17 integer vector ops per lane and block:
 //   four high bytes at once: (x & 0x07070707) + eh * 0x01010101 + ((x & 0x08080808) << 4), then v_perm interleaves.
@@ -47,46 +47,28 @@ struct CwReg { u32x3 c; };
 // no vector-memory instruction (a per-lane byte load per block, or a per-unit gather, cost 2-4 us per launch) and the base
 // replication / escape test below become scalar work. `word` = the aligned dword holding the byte.
 typedef __attribute__((address_space(4))) const uint32_t cw_cu32;
-__device__ __forceinline__ uint32_t cw_base_word(const uint8_t* emin, size_t blk) {   // two bytes per block: eh | flag << 7, elow
-  return ((cw_cu32*)(uintptr_t)emin)[blk >> 1];
+__device__ __forceinline__ uint32_t cw_base_word(const uint8_t* emin, size_t blk) {
+  return ((cw_cu32*)(uintptr_t)emin)[blk >> 2];
 }
-__device__ __forceinline__ uint32_t cw_base_byte(uint32_t word, size_t blk) { return (word >> (16 * (blk & 1))) & 0xffffu; }
+__device__ __forceinline__ uint32_t cw_base_byte(uint32_t word, size_t blk) { return (word >> (8 * (blk & 3))) & 0xffu; }
 __device__ __forceinline__ uint32_t cw_high4(uint32_t x, uint32_t eh4) {   // four 4-bit fields (one per byte) -> four high bytes
   return ((x & 0x07070707u) + eh4) + ((x & 0x08080808u) << 4);
 }
-// e: the block's two bytes of GemvArgs::emin, wave-uniform (an SGPR: base replication and the escape tests are scalar work)
+// e: the block's byte of GemvArgs::emin, wave-uniform (an SGPR: the base replication and the escape test are scalar work)
 __device__ __forceinline__ bf16x8 cw_decode(const CwReg& r, uint32_t e, const uint16_t* sh_patch) {
   uint32_t eh4 = e & 0x7fu;
   eh4 |= eh4 << 8;
   eh4 |= eh4 << 16;
-  uint32_t ha = cw_high4(r.c[2] & 0x0f0f0f0fu, eh4), hb = cw_high4((r.c[2] >> 4) & 0x0f0f0f0fu, eh4);
-  uint32_t l0 = r.c[0], l1 = r.c[1];
-  uint32_t z0 = 0u, z1 = 0u;
-  const bool flagged = (e & 0x80u) != 0u, table = (e >> 8) == 0xffu;
-  if (flagged) {                                                         // ~4 % of blocks
+  const uint32_t ha = cw_high4(r.c[2] & 0x0f0f0f0fu, eh4), hb = cw_high4((r.c[2] >> 4) & 0x0f0f0f0fu, eh4);
+  u32x4 t = {__builtin_amdgcn_perm(ha, r.c[0], 0x05010400u), __builtin_amdgcn_perm(ha, r.c[0], 0x07030602u),
+             __builtin_amdgcn_perm(hb, r.c[1], 0x05010400u), __builtin_amdgcn_perm(hb, r.c[1], 0x07030602u)};
+  if (e & 0x80u) {                                                       // rare (~4 % of blocks): this block has escaped elements
     // which of this lane's eight elements carry exponent code 0? y = the 4-bit codes, one per byte; z = 0x80 in every zero byte
-    const uint32_t y0 = (r.c[2] & 0x07070707u) | ((l0 >> 4) & 0x08080808u);
-    const uint32_t y1 = ((r.c[2] >> 4) & 0x07070707u) | ((l1 >> 4) & 0x08080808u);
-    z0 = ((y0 + 0x7f7f7f7fu) & 0x80808080u) ^ 0x80808080u;
-    z1 = ((y1 + 0x7f7f7f7fu) & 0x80808080u) ^ 0x80808080u;
-    if (!table) {                                                        // their exponent is the block's elow, sign and mantissa are in place
-      const uint32_t elow = e >> 8;
-      uint32_t elh4 = elow >> 1;
-      elh4 |= elh4 << 8;
-      elh4 |= elh4 << 16;
-      const uint32_t el0 = (elow & 1u) ? 0x80808080u : 0u;
-      const uint32_t m0 = ((z0 - (z0 >> 7)) | z0) & 0x7f7f7f7fu, m1 = ((z1 - (z1 >> 7)) | z1) & 0x7f7f7f7fu;   // 0x7f per escaped byte
-      ha = (ha & ~m0) | (elh4 & m0);
-      hb = (hb & ~m1) | (elh4 & m1);
-      l0 |= z0 & el0;
-      l1 |= z1 & el0;
-    }
-  }
-  u32x4 t = {__builtin_amdgcn_perm(ha, l0, 0x05010400u), __builtin_amdgcn_perm(ha, l0, 0x07030602u),
-             __builtin_amdgcn_perm(hb, l1, 0x05010400u), __builtin_amdgcn_perm(hb, l1, 0x07030602u)};
-  if (flagged && table) {                                                // ~0.1 % of blocks: true values from the unit's patch table
+    const uint32_t y0 = (r.c[2] & 0x07070707u) | ((r.c[0] >> 4) & 0x08080808u);
+    const uint32_t y1 = ((r.c[2] >> 4) & 0x07070707u) | ((r.c[1] >> 4) & 0x08080808u);
+    const uint32_t z0 = ((y0 + 0x7f7f7f7fu) & 0x80808080u) ^ 0x80808080u, z1 = ((y1 + 0x7f7f7f7fu) & 0x80808080u) ^ 0x80808080u;
     uint64_t zz = (uint64_t)z0 | ((uint64_t)z1 << 32);
-    while (zz) {                                                         // only the lanes that hold one
+    while (zz) {                                                         // only the lanes that hold one; usually one lane, one element
       const int k = (__ffsll((unsigned long long)zz) - 1) >> 3;          // element 0..7
       zz &= zz - 1;
       const int sh8 = 8 * (k & 3);
@@ -129,39 +111,18 @@ __global__ __launch_bounds__(64) void cw_compress_kernel(const bf16_t* __restric
   }
   const int eh = emax > 15 ? (emax - 14) >> 1 : 0;                     // smallest eh with 2 eh + 15 >= emax
   const bool flagged = emn < 2 * eh;                                   // some element lies below the block's 16 binades
-  // flagged: elements with exponent <= 2 eh are escaped (code 0 is the marker). One common exponent -> elow; else the patch table.
-  int lo_max = -1, lo_min = 256;
-  if (flagged) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int ex = (el[j] >> 7) & 0xff;
-      if (ex <= 2 * eh) { lo_max = ex > lo_max ? ex : lo_max; lo_min = ex < lo_min ? ex : lo_min; }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const int a = __shfl_xor(lo_max, o, 64), b = __shfl_xor(lo_min, o, 64);
-      lo_max = a > lo_max ? a : lo_max;
-      lo_min = b < lo_min ? b : lo_min;
-    }
-  }
-  const bool table = flagged && lo_max != lo_min;
   const int unit = (int)(blk / KT) / nt_unit;
   uint32_t lo[2] = {0u, 0u}, hn = 0u;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int ex = (el[j] >> 7) & 0xff;
     uint32_t low = el[j] & 0xffu, nib;
-    if (flagged && ex <= 2 * eh) {
-      if (table) {                                                     // an index into the unit's patch table in the sign / mantissa fields
-        const int idx = atomicAdd(&cnt[unit], 1);
-        if (idx < 256) patch[(size_t)unit * 256 + idx] = (uint16_t)el[j];
-        else *overflow = 1;
-        low = (uint32_t)idx & 0x7fu;
-        nib = ((uint32_t)idx >> 4) & 0x8u;
-      } else {                                                         // sign and mantissa in place, exponent = the block's elow
-        low = el[j] & 0x7fu;
-        nib = (el[j] >> 12) & 0x8u;
-      }
+    if (flagged && ex <= 2 * eh) {                                     // escaped: exponent code 0 + an index into the unit's patch table
+      const int idx = atomicAdd(&cnt[unit], 1);
+      if (idx < 256) patch[(size_t)unit * 256 + idx] = (uint16_t)el[j];
+      else *overflow = 1;
+      low = (uint32_t)idx & 0x7fu;
+      nib = ((uint32_t)idx >> 4) & 0x8u;
     } else {
       nib = ((el[j] >> 12) & 0x8u) | (uint32_t)((ex - 2 * eh) >> 1);
     }
@@ -170,10 +131,7 @@ __global__ __launch_bounds__(64) void cw_compress_kernel(const bf16_t* __restric
   }
   uint32_t* dst = (uint32_t*)(Wc + blk * 768 + lane * 12);
   dst[0] = lo[0]; dst[1] = lo[1]; dst[2] = hn;
-  if (lane == 0) {
-    emin[2 * blk] = (uint8_t)(eh | (flagged ? 0x80 : 0));
-    emin[2 * blk + 1] = (uint8_t)(table ? 0xff : (flagged ? lo_max : 0));
-  }
+  if (lane == 0) emin[blk] = (uint8_t)(eh | (flagged ? 0x80 : 0));
 }
 
 template <bool CW> struct WFrag { bf16x8 v; };

@@ -60,16 +60,15 @@ struct GemvArgs {
   bf16_t* C_xf;
   // Losslessly compressed weights (gemv.hip "12-bit blocks"): when Wc is non-null the kernel streams Wc / emin instead of Wp.
   // Wc: per 1-KiB fragment block 768 B (lane l: 12 B = its 8 elements at 12 bits: sign, 4-bit exponent offset, 7-bit mantissa);
-  // emin: two bytes per block: [0] bits 0-6 = (smallest coded exponent field) / 2, bit 7 = the block has escaped elements;
-  // [1] = the exponent field of its escaped elements, 0xff = they index the patch table;
-  // patch: true bf16 bits of the escaped elements of table-mode blocks, 256 entries per GEMV unit
+  // emin[block]: bits 0-6 = (smallest coded exponent field) / 2, bit 7 = the block has escaped elements;
+  // patch: true bf16 bits of the escaped elements, 256 entries per GEMV unit
   const uint8_t* Wc = nullptr; const uint8_t* emin = nullptr; const uint16_t* patch = nullptr;
   // optional (host side only): HIP events that bracket exactly this kernel's execution (hipExtLaunchKernelGGL start /
   // stop events = the dispatch's own timestamps, what rocprofv3's kernel trace reports), for orc_profile_read
   void* ev_start; void* ev_stop;
 };
 hipError_t launch_gemv_ex(const GemvArgs& a, int epi, int variant, hipStream_t s);
-// lossless 12-bit compression of a packed matrix for the decode GEMVs (gemv.hip): Wc N*K*3/2 bytes, emin 2*N/16*K/32 bytes (+3 pad),
+// lossless 12-bit compression of a packed matrix for the decode GEMVs (gemv.hip): Wc N*K*3/2 bytes, emin N/16*K/32 bytes (+3 pad),
 // patch (N/16/nt_unit)*256 uint16, cnt N/16/nt_unit ints; *overflow_dev is set when a unit has more than 256 escapes
 int gemv_unit_tiles(int epi, int N);
 hipError_t launch_compress_weight(const bf16_t* Wp, int N, int K, int nt_unit, uint8_t* Wc, uint8_t* emin, uint16_t* patch, int* cnt,

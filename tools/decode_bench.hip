@@ -57,7 +57,7 @@ __global__ void gauss_kernel(uint16_t* p, size_t n, uint32_t seed) {
 }
 
 __global__ void clear_flags_kernel(uint8_t* e, size_t nblk) {   // timing experiment: same bases, no block flagged
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nblk; i += (size_t)gridDim.x * blockDim.x) e[2 * i] &= 0x7f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nblk; i += (size_t)gridDim.x * blockDim.x) e[i] &= 0x7f;
 }
 struct Shape { const char* name; int N, K, epi; };
 int gemv_unit_tiles(int epi, int N);
@@ -219,7 +219,7 @@ int main(int argc, char** argv) {
         int* cnt;
         const int ntu = gemv_unit_tiles(sh.epi, sh.N), un = sh.N / 16 / ntu;
         const size_t nblk = (size_t)sh.N / 16 * sh.K / 32;
-        CK(hipMalloc((void**)&gw, wbytes)); CK(hipMalloc((void**)&gc, nblk * 768)); CK(hipMalloc((void**)&ge, 2 * nblk + 8));
+        CK(hipMalloc((void**)&gw, wbytes)); CK(hipMalloc((void**)&gc, nblk * 768)); CK(hipMalloc((void**)&ge, nblk + 8));
         CK(hipMalloc((void**)&gp, (size_t)un * 512)); CK(hipMalloc((void**)&cnt, (size_t)(un + 1) * 4));
         hipLaunchKernelGGL(gauss_kernel, dim3(4096), dim3(256), 0, 0, gw, wbytes / 2, 99u);
         CK(hipMemset(cnt + un, 0, 4));
