@@ -489,9 +489,9 @@ def main():
                             'frac_of_hbm_peak': dec_bytes / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             'streamed_bytes': dec_phys, 'streamed_GBps': dec_phys / (dec_ms * 1e-3) / 1e9,
                             'streamed_frac_of_hbm_peak': dec_phys / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-            'roofline': {'kernel': ('gemv_pers_kernel<2,SWIGLU,16,2,1,cw> (decode gate/up projection, 22016x4096 bf16 weights streamed as lossless '
+            'roofline': {'kernel': ('gemv_pers_kernel<2,SWIGLU,8,2,1,cw> (decode gate/up projection, 22016x4096 bf16 weights streamed as lossless '
                                     '12-bit blocks)' if gu_phys < prof_bytes else
-                                    'gemv_pers_kernel<2,SWIGLU,16,1,1> (decode gate/up projection, 22016x4096 bf16 weights)'), 'bound': 'hbm',
+                                    'gemv_pers_kernel<2,SWIGLU,8,1,1> (decode gate/up projection, 22016x4096 bf16 weights)'), 'bound': 'hbm',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'traffic_source': traffic_src, 'launches_timed': prof_n, 'avg_launch_us': avg_us,
                          'algorithmic_bytes_per_launch': prof_bytes,

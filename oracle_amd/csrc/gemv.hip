@@ -700,10 +700,13 @@ hipError_t pick_default(const GemvArgs& a, int ntiles, hipStream_t s) {
   } else if constexpr (EPI == EPI_ROPE_KV) {
     go_pers<NT, EPI, 4, 1>(a, ntiles, units, s);
   } else if constexpr (EPI == EPI_SWIGLU) {
-    // 16 waves: the compressed stream is partly bound by the decode's vector work (12 waves: 24.7 us, 16: 23.8; in the engine
-    // 28.1 -> 26.6 us); the bf16 fallback keeps the same K split (so the same bits) and pays 2 us for it (31.8 vs 29.8 us)
-    if (a.Wc) go_pers<NT, EPI, 16, 2>(a, ntiles, grid, s);
-    else go_pers<NT, EPI, 16, 1>(a, ntiles, grid, s);
+    // Compressed stream: about two 8-wave workgroups per CU (460-500 workgroups, one or two units each; the hardware back-fills)
+    // instead of one 16-wave workgroup: more waves per CU for the decode's vector work, and a flagged block's LDS round trip
+    // holds 8 waves at the unit barrier instead of 16 (tools/decode_bench: 22.7 vs 23.6 us; 12 waves on 230 workgroups: 24.8).
+    // The bf16 fallback keeps the same K split (so the same bits).
+    const int grid2 = units < 480 ? units : 480;
+    if (a.Wc) go_pers<NT, EPI, 8, 2>(a, ntiles, grid2, s);
+    else go_pers<NT, EPI, 8, 1>(a, ntiles, grid2, s);
   } else {
     const int per2 = (units + 511) / 512;
     go_pers<NT, EPI, 8, 1>(a, ntiles, a.Wc ? (units + per2 - 1) / per2 : grid, s);   // lm_head compressed: grid 500: 32.3 vs 39.4 us

@@ -236,15 +236,27 @@ int main(int argc, char** argv) {
         float us0 = time_it([&](int i) { hipError_t e = launch_gemv_ex(b, sh.epi, 0, s); if (e != hipSuccess) err = e; });
         printf("%s compressed Gaussian weights: %ld escapes (%.2e per element, max %d per unit, overflow %d): %7.2f us; same bytes with no block flagged: %7.2f us%s\n",
                sh.name, esc, (double)esc / ((double)sh.N * sh.K), mx, hc[un], us, us0, err != hipSuccess ? "  LAUNCH ERROR" : "");
+        if (sh.epi == EPI_SWIGLU || sh.epi == EPI_F32) {   // persistent configurations on the real data (flags were cleared above: recompress)
+          CK(hipMemset(cnt + un, 0, 4));
+          CK(launch_compress_weight(gw, sh.N, sh.K, ntu, gc, ge, gp, cnt, cnt + un, 0));
+          for (int waves : {8, 12, 16})
+            for (int u : {1, 2})
+              for (int grid : {230, 250, 344, 500}) {
+                if (grid > un) continue;
+                hipError_t e2 = hipSuccess;
+                float t = time_it([&](int i) { hipError_t e = launch_gemv_pers(b, sh.epi, waves, u, grid, s); if (e != hipSuccess) e2 = e; });
+                if (e2 != hipSuccess) { (void)hipGetLastError(); continue; }
+                printf("%s Gaussian compressed pers W%-2d U%d grid %3d : %7.2f us\n", sh.name, waves, u, grid, t);
+              }
+        }
         CK(hipFree(gw)); CK(hipFree(gc)); CK(hipFree(ge)); CK(hipFree(gp)); CK(hipFree(cnt));
       }
       // persistent sweep on the compressed stream
       const int units = sh.N / 16 / (sh.epi == EPI_RESIDUAL ? 1 : (sh.epi == EPI_ROPE_KV ? 3 : 2));
       for (int waves : {8, 12, 16})
         for (int u : {1, 2})
-          for (int div : {1, 2, 3, 4}) {
-            const int grid = (units + div - 1) / div;
-            if (grid > 512 || grid < 128) continue;
+          for (int grid : {units, (units + 1) / 2, (units + 2) / 3, (units + 3) / 4, 460, 500, 512}) {
+            if (grid > 1024 || grid < 128 || grid > units) continue;
             hipError_t err = hipSuccess;
             float us = time_it([&](int i) {
               const size_t off = (((size_t)i * wbytes) % (pool_bytes - wbytes)) & ~(size_t)1023;
