@@ -253,7 +253,7 @@ void free_owned(orc_engine* e, void* p) {
 // Decode GEMVs are HBM-bound on the weight stream and their vector ALUs idle: give W a lossless 12-bit copy (768 B per 1-KiB
 // fragment block, bit-exact decode in the kernel, gemv.hip) that the decode launches stream instead. epi = the epilogue the
 // decode GEMV of this matrix runs with (it fixes the unit size of the patch tables). drop_plain: the bf16 copy is used by
-// nothing else (the norm-folded decode copies) and is freed. A matrix with a unit of more than 256 out-of-range elements
+// nothing else (the norm-folded decode copies) and is freed. A matrix with a unit of more than 254 non-zero out-of-range elements
 // (never seen with Gaussian or trained weights; possible with crafted ones) silently stays uncompressed.
 int compress_for_decode(orc_engine* e, Packed* W, int epi, bool drop_plain) {
   if (!e->compress_decode || !W->p) return 0;
@@ -1095,7 +1095,7 @@ extern "C" int orc_test_gemm(const void* x, int M, int K, const void* w, int N, 
     HIPCHK(hipFree(wc)); HIPCHK(hipFree(em)); HIPCHK(hipFree(patch)); HIPCHK(hipFree(cnt));
     HIPCHK(hipFree(wp));
     if (rm) HIPCHK(hipFree(rm));
-    if (overflow) return fail("orc_test_gemm", "weights not compressible: a unit has more than 256 out-of-range elements");
+    if (overflow) return fail("orc_test_gemm", "weights not compressible: a unit has more than 254 non-zero out-of-range elements");
     if (err != hipSuccess) return fail("orc_test_gemm", hipGetErrorString(err));
     return 0;
   }

@@ -86,7 +86,7 @@ __device__ __forceinline__ bf16x8 cw_decode(const CwReg& r, uint32_t e, const ui
 
 // Compressor (orc_engine_finalize, once per matrix): one wave per 1-KiB block of the packed bf16 matrix. nt_unit = n-tiles per
 // GEMV unit (the patch table is per unit). cnt[unit] (zeroed by the caller) counts escapes; *overflow is set if a unit
-// has more than 256 of them (the caller then keeps the matrix uncompressed).
+// has more than 254 non-zero ones (the caller then keeps the matrix uncompressed); escaped zeros share two constant entries.
 __global__ __launch_bounds__(64) void cw_compress_kernel(const bf16_t* __restrict__ Wp, int KT, int nt_unit, uint8_t* __restrict__ Wc,
                                                          uint8_t* __restrict__ emin, uint16_t* __restrict__ patch,
                                                          int* __restrict__ cnt, int* __restrict__ overflow) {
@@ -118,9 +118,15 @@ __global__ __launch_bounds__(64) void cw_compress_kernel(const bf16_t* __restric
     const int ex = (el[j] >> 7) & 0xff;
     uint32_t low = el[j] & 0xffu, nib;
     if (flagged && ex <= 2 * eh) {                                     // escaped: exponent code 0 + an index into the unit's patch table
-      const int idx = atomicAdd(&cnt[unit], 1);
-      if (idx < 256) patch[(size_t)unit * 256 + idx] = (uint16_t)el[j];
-      else *overflow = 1;
+      int idx;
+      if ((el[j] & 0x7fffu) == 0u) {                                   // +0 / -0 (pruned or padded weights): the two constant entries,
+        idx = (el[j] & 0x8000u) ? 0xff : 0x7f;                         // any number of them costs no table space
+      } else {
+        const int n = atomicAdd(&cnt[unit], 1);
+        idx = n < 0x7f ? n : n + 1;                                    // 254 free entries: 0..0x7e, 0x80..0xfe
+        if (n < 254) patch[(size_t)unit * 256 + idx] = (uint16_t)el[j];
+        else *overflow = 1;
+      }
       low = (uint32_t)idx & 0x7fu;
       nib = ((uint32_t)idx >> 4) & 0x8u;
     } else {
@@ -131,7 +137,13 @@ __global__ __launch_bounds__(64) void cw_compress_kernel(const bf16_t* __restric
   }
   uint32_t* dst = (uint32_t*)(Wc + blk * 768 + lane * 12);
   dst[0] = lo[0]; dst[1] = lo[1]; dst[2] = hn;
-  if (lane == 0) emin[blk] = (uint8_t)(eh | (flagged ? 0x80 : 0));
+  if (lane == 0) {
+    emin[blk] = (uint8_t)(eh | (flagged ? 0x80 : 0));
+    if (blk % ((size_t)KT * nt_unit) == 0) {                            // the unit's constant entries
+      patch[(size_t)unit * 256 + 0x7f] = 0x0000u;
+      patch[(size_t)unit * 256 + 0xff] = 0x8000u;
+    }
+  }
 }
 
 template <bool CW> struct WFrag { bf16x8 v; };

@@ -69,7 +69,7 @@ struct GemvArgs {
 };
 hipError_t launch_gemv_ex(const GemvArgs& a, int epi, int variant, hipStream_t s);
 // lossless 12-bit compression of a packed matrix for the decode GEMVs (gemv.hip): Wc N*K*3/2 bytes, emin N/16*K/32 bytes (+3 pad),
-// patch (N/16/nt_unit)*256 uint16, cnt N/16/nt_unit ints; *overflow_dev is set when a unit has more than 256 escapes
+// patch (N/16/nt_unit)*256 uint16, cnt N/16/nt_unit ints; *overflow_dev is set when a unit has more than 254 non-zero escapes (escaped zeros share two constant entries)
 int gemv_unit_tiles(int epi, int N);
 hipError_t launch_compress_weight(const bf16_t* Wp, int N, int K, int nt_unit, uint8_t* Wc, uint8_t* emin, uint16_t* patch, int* cnt,
                                   int* overflow_dev, hipStream_t s);

@@ -258,6 +258,8 @@ def _nasty_weights(N, K, seed):
         w[n, k] = 90.0
     w[32:48] = 0.0
     w[5, 64:96] = 0.0
+    w[64:80][torch.rand(16, K, generator=g) < 0.4] = 0.0        # a pruned tile: thousands of zeros in one unit (they need no table space)
+    w[81, ::2] = -0.0
     return w.to(torch.bfloat16)
 
 
@@ -281,7 +283,7 @@ def test_compressed_weight_stream_is_bit_exact(epi, N, K, M):
 
 
 def test_compressed_weight_stream_refuses_more_than_256_escapes_per_unit():
-    """A unit (16 rows x K of a one-tile kernel) whose blocks need more than 256 patch entries cannot be compressed: the hook
+    """A unit (16 rows x K of a one-tile kernel) whose blocks need more than 254 non-zero patch entries cannot be compressed: the hook
     reports it (the engine then keeps that matrix in bf16, engine.hip compress_for_decode)."""
     from oracle_amd import engine as E
     d = _dev()
