@@ -362,6 +362,152 @@ __global__ __launch_bounds__(WAVES * 64) void decode_attn_kernel(DecodeAttnArgs 
   }
 }
 
+// ---- r3: the same lane layout and the same rounding points, as a software pipeline. decode_attn_kernel above issues a step's
+// K and V loads, waits, computes, and only then requests the next step (a wave has nothing in flight while it runs its
+// dependent dot -> 4 LDS-crossbar shuffles (each waited for) -> exp -> accumulate chain: .s of r2). Here:
+//   * K / V rows come through buffer descriptors whose range ends at the row's last cached key: the load of step i + 1 is issued
+//     unconditionally BEFORE step i is computed (two named register sets, counted vmcnt), keys past the end return zeros
+//     without a memory request and without a branch;
+//   * the 16-lane dot-product reduction runs on DPP row operations (4 v_add_f32_dpp, no LDS traffic, no lgkmcnt wait) and the
+//     products on v_dot2c_f32_bf16 (q stays packed bf16).
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ float row16_sum(float v) {   // sum over the 16 lanes of a DPP row, in every lane of the row
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));   // row_mirror
+  return v;
+}
+// (by value on purpose: __builtin_bit_cast applied directly to a vector-element expression read element 0 for every index -- hipcc 7.2)
+__device__ __forceinline__ bf16x2_t as_bf2(uint32_t x) { return __builtin_bit_cast(bf16x2_t, x); }
+template <int WAVES, int U>
+__global__ __launch_bounds__(WAVES * 64) void decode_attn_pipe_kernel(DecodeAttnArgs a) {
+  __shared__ float sh_m[WAVES], sh_l[WAVES];
+  __shared__ __attribute__((aligned(16))) float sh_acc[WAVES][128];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = lane >> 4, c = lane & 15;
+  const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z, nsplit = gridDim.z;
+  const int sl = a.map.slot[b];
+  const int len = sl < 0 ? 1 : a.cur_len[sl];
+  const int kb = sl < 0 ? 0 : a.kbeg[sl];
+  if (sl < 0 || (a.unfinished && !a.unfinished[sl])) {   // inactive or finished row (its tokens are pad): no cache read at all
+    if (tid < 128) {
+      if (nsplit == 1) {
+        a.O[a.o_xf ? xf_off_rows(b, h * 128 + tid, a.H * 128) : (size_t)b * a.o_bs + h * 128 + tid] = 0;
+      } else {
+        float* pp = a.part + (((size_t)b * a.H + h) * DECODE_NSPLIT + sp) * 130;
+        if (tid == 0) { pp[0] = -INFINITY; pp[1] = 0.f; }
+        pp[2 + tid] = 0.f;
+      }
+    }
+    return;
+  }
+  const int n = len - kb;
+  const int per = (n + nsplit - 1) / nsplit;
+  const int k_lo = kb + sp * per;
+  const int k_hi = (k_lo + per < len) ? k_lo + per : len;
+
+  const u32x4 qv = *(const u32x4*)(a.Q + (size_t)b * a.q_bs + h * 128 + c * 8);
+  // descriptors over this (slot, head)'s rows [0, k_hi): a key index >= k_hi is out of range
+  const bf16_t* kbase = a.Kc + (size_t)sl * a.c_bs + (size_t)h * a.c_hs;
+  const bf16_t* vbase = a.Vc + (size_t)sl * a.c_bs + (size_t)h * a.c_hs;
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, k_hi * 256, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, k_hi * 256, 0x00020000);
+  const int loff = kq * 256 + c * 16;                                 // this lane's bytes inside a 4-key step
+  constexpr int STEP = 4 * WAVES;                                     // keys per workgroup step
+
+  float m = -INFINITY, l = 0.f, acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+
+  // the whole offset travels in the per-lane register (the range check then needs nothing from the scalar offset)
+  auto load = [&](u32x4 (&kd)[U], u32x4 (&vd)[U], int base) {        // keys base + u * STEP + kq (base wave-uniform)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int off = loff + (base + u * STEP) * 256;
+      kd[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, off, 0, 2));
+      vd[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, off, 0, 2));
+    }
+  };
+  auto step = [&](const u32x4 (&kd)[U], const u32x4 (&vd)[U], int base) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float d = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d = __builtin_amdgcn_fdot2_f32_bf16(as_bf2(qv[j]), as_bf2(kd[u][j]), d, false);
+      d = row16_sum(d);
+      const bool ok = base + u * STEP + kq < k_hi;
+      const float sc = ok ? rbf(rbf(d) * a.scale) : -INFINITY;
+      const float m_new = fmaxf(m, sc);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = rescale(m, m_use);
+      const float p = (sc == -INFINITY) ? 0.f : __expf(sc - m_use);
+      const float pb = rbf(p);
+      l = l * alpha + p;
+      m = m_new;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[2 * j] = acc[2 * j] * alpha + pb * lo_bf(vd[u][j]);
+        acc[2 * j + 1] = acc[2 * j + 1] * alpha + pb * hi_bf(vd[u][j]);
+      }
+    }
+  };
+  {
+    u32x4 kA[U], vA[U], kB[U], vB[U];
+    int base = k_lo + w * 4;
+    load(kA, vA, base);
+    while (base < k_hi) {
+      load(kB, vB, base + U * STEP);
+      step(kA, vA, base);
+      base += U * STEP;
+      if (base >= k_hi) break;
+      load(kA, vA, base + U * STEP);
+      step(kB, vB, base);
+      base += U * STEP;
+    }
+  }
+  // merge the 4 key slots of the wave
+#pragma unroll
+  for (int off = 16; off <= 32; off <<= 1) {
+    const float m_o = __shfl_xor(m, off, 64);
+    const float l_o = __shfl_xor(l, off, 64);
+    const float m_n = fmaxf(m, m_o);
+    const float m_use = (m_n == -INFINITY) ? 0.f : m_n;
+    const float a0 = rescale(m, m_use), a1 = rescale(m_o, m_use);
+    l = l * a0 + l_o * a1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = acc[j] * a0 + __shfl_xor(acc[j], off, 64) * a1;
+    m = m_n;
+  }
+  if (kq == 0) {
+    if (c == 0) { sh_m[w] = m; sh_l[w] = l; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sh_acc[w][c * 8 + j] = acc[j];
+  }
+  __syncthreads();
+  if (tid < 128) {
+    float mm = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < WAVES; ++i) mm = fmaxf(mm, sh_m[i]);
+    const float m_use = (mm == -INFINITY) ? 0.f : mm;
+    float ll = 0.f, av = 0.f;
+#pragma unroll
+    for (int i = 0; i < WAVES; ++i) {
+      const float sc = rescale(sh_m[i], m_use);
+      ll += sh_l[i] * sc;
+      av += sh_acc[i][tid] * sc;
+    }
+    if (nsplit == 1) {
+      a.O[a.o_xf ? xf_off_rows(b, h * 128 + tid, a.H * 128) : (size_t)b * a.o_bs + h * 128 + tid] = f2bf(ll > 0.f ? av / ll : 0.f);
+    } else {
+      float* pp = a.part + (((size_t)b * a.H + h) * DECODE_NSPLIT + sp) * 130;
+      if (tid == 0) { pp[0] = mm; pp[1] = ll; }
+      pp[2 + tid] = av;
+    }
+  }
+}
+
 __global__ __launch_bounds__(128) void decode_attn_combine_kernel(DecodeAttnArgs a, int nsplit) {
   const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const float* pp = a.part + ((size_t)b * a.H + h) * DECODE_NSPLIT * 130;
@@ -398,7 +544,15 @@ hipError_t launch_decode_attention(const DecodeAttnArgs& a, hipStream_t s, int v
   if (a.B <= 0) return hipSuccess;
   if (a.B * a.H >= 192) {   // one workgroup per (row, head) fills the chip without a KV split
     switch (variant) {
+      case 100: hipLaunchKernelGGL((decode_attn_kernel<16, 1>), dim3(a.H, a.B, 1), dim3(1024), 0, s, a); break;   // r2 kernel (tests / tools)
 #ifdef GEMV_ALL_VARIANTS
+      case 12: hipLaunchKernelGGL((decode_attn_pipe_kernel<16, 1>), dim3(a.H, a.B, 1), dim3(1024), 0, s, a); break;
+      case 13: hipLaunchKernelGGL((decode_attn_pipe_kernel<16, 2>), dim3(a.H, a.B, 1), dim3(1024), 0, s, a); break;
+      case 14: hipLaunchKernelGGL((decode_attn_pipe_kernel<8, 1>), dim3(a.H, a.B, 1), dim3(512), 0, s, a); break;
+      case 15: hipLaunchKernelGGL((decode_attn_pipe_kernel<8, 2>), dim3(a.H, a.B, 1), dim3(512), 0, s, a); break;
+      case 16: hipLaunchKernelGGL((decode_attn_pipe_kernel<8, 4>), dim3(a.H, a.B, 1), dim3(512), 0, s, a); break;
+      case 17: hipLaunchKernelGGL((decode_attn_pipe_kernel<4, 2>), dim3(a.H, a.B, 1), dim3(256), 0, s, a); break;
+      case 18: hipLaunchKernelGGL((decode_attn_pipe_kernel<4, 4>), dim3(a.H, a.B, 1), dim3(256), 0, s, a); break;
       case 1: hipLaunchKernelGGL((decode_attn_kernel<16, 4>), dim3(a.H, a.B, 1), dim3(1024), 0, s, a); break;
       case 2: hipLaunchKernelGGL((decode_attn_kernel<16, 2>), dim3(a.H, a.B, 1), dim3(1024), 0, s, a); break;
       case 3: hipLaunchKernelGGL((decode_attn_kernel<16, 1>), dim3(a.H, a.B, 1), dim3(1024), 0, s, a); break;
@@ -411,8 +565,8 @@ hipError_t launch_decode_attention(const DecodeAttnArgs& a, hipStream_t s, int v
       case 10: hipLaunchKernelGGL((decode_attn_kernel<2, 4>), dim3(a.H, a.B, 1), dim3(128), 0, s, a); break;
       case 11: hipLaunchKernelGGL((decode_attn_kernel<2, 8>), dim3(a.H, a.B, 1), dim3(128), 0, s, a); break;
 #endif
-      // 16 waves, one 4-key step in flight per wave: deeper unrolls only oversubscribe the memory system (tools/decode_bench)
-      default: hipLaunchKernelGGL((decode_attn_kernel<16, 1>), dim3(a.H, a.B, 1), dim3(1024), 0, s, a); break;
+      // 16 waves, 4-key steps, the next step in flight while this one is computed (r3: decode_attn_pipe_kernel)
+      default: hipLaunchKernelGGL((decode_attn_pipe_kernel<16, 1>), dim3(a.H, a.B, 1), dim3(1024), 0, s, a); break;
     }
   } else {
     // few (row, head) pairs: split every key range so that about one workgroup per CU streams the cache
@@ -427,7 +581,8 @@ hipError_t launch_decode_attention(const DecodeAttnArgs& a, hipStream_t s, int v
       case 5: hipLaunchKernelGGL((decode_attn_kernel<16, 2>), dim3(a.H, a.B, nsplit), dim3(1024), 0, s, a); break;
       case 6: hipLaunchKernelGGL((decode_attn_kernel<4, 4>), dim3(a.H, a.B, nsplit), dim3(256), 0, s, a); break;
 #endif
-      default: hipLaunchKernelGGL((decode_attn_kernel<16, 1>), dim3(a.H, a.B, nsplit), dim3(1024), 0, s, a); break;
+      case 100: hipLaunchKernelGGL((decode_attn_kernel<16, 1>), dim3(a.H, a.B, nsplit), dim3(1024), 0, s, a); break;   // r2 kernel
+      default: hipLaunchKernelGGL((decode_attn_pipe_kernel<16, 1>), dim3(a.H, a.B, nsplit), dim3(1024), 0, s, a); break;
     }
     hipLaunchKernelGGL(decode_attn_combine_kernel, dim3(a.H, a.B), dim3(128), 0, s, a, nsplit);
   }

@@ -1066,8 +1066,14 @@ extern "C" int orc_test_gemm(const void* x, int M, int K, const void* w, int N, 
   a.ldr = nout; a.C = out; a.ldc = nout; a.M = M; a.N = Np; a.K = Kp; a.Nvalid = nout;
   // use_gemv: 0 = GEMM (automatic kernel choice), 1 = decode GEMV, 2 = 128^2 register-staged GEMM, 3 / 4 = LDS-DMA GEMM with
   // 256-row / 128-row tiles only, 5 = decode GEMV on the lossless 12-bit copy of the weights (must equal 1 bit for bit),
+  // 6 / 7 = 1 / 5 on the r2 kernels (branchy k-loop; must equal the pipelined kernels bit for bit),
   // 100 + n = LDS-DMA GEMM with n 256-row m-tiles and 128-row tiles for the remaining rows
   hipError_t err;
+  struct LegacyGuard { ~LegacyGuard() { gemv_force_legacy(0); } } legacy_guard;
+  if (use_gemv == 6 || use_gemv == 7) {
+    gemv_force_legacy(1);
+    use_gemv = use_gemv == 6 ? 1 : 5;
+  }
   if (use_gemv == 5) {
     const int nt_unit = gemv_unit_tiles(epi, Np), units = Np / 16 / nt_unit;
     const size_t nblk = (size_t)(Np / 16) * (Kp / 32);

@@ -170,9 +170,10 @@ __device__ __forceinline__ void scale_load(const GemvArgs& a, ScaleRegs<RH>& r, 
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if (4 * i < per) r.v[hf][i] = *(const f32x4*)(p + 4 * i);
-    } else {   // narrow models (n_part < 16 * SW): per is 1 or 2
-      r.v[hf][0][0] = p[0];
-      if (per > 1) r.v[hf][0][1] = p[1];
+    } else {   // any other slice length (d_model / 256 not a multiple of 4, e.g. 768, 1280, 2560): element by element
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (j < per) r.v[hf][j >> 2][j & 3] = p[j];
     }
   }
 }
@@ -490,6 +491,171 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs a) {
   }
 }
 
+// ---- r3: the same unit / K split / summation order as gemv_kernel<.., KMODE 1, ..> (so the same output bits), but the
+// k-loop is a real software pipeline. In gemv_kernel every load sits behind a wave-uniform "is this k-tile mine?" branch and
+// the activation loads behind a per-lane row test; hipcc then cannot count its loads and drains the queue (`s_waitcnt
+// vmcnt(0)`) at the top of every iteration -- both register buffers are waited for together, nothing is in flight while a
+// wave decodes and multiplies -- and the block's side byte (`s_load` + shift) was waited for right where it was requested,
+// in front of the activation load (.s of r2). Here:
+//   * the main loop runs over FULL steps only (every load unconditional; the ragged end is peeled into one conditional
+//     round), so the waits are counted: `vmcnt((NT + RH) * U * (NB - 1))` in front of a buffer's MFMAs;
+//   * activation fragments come through a buffer descriptor: lanes of rows >= M carry an out-of-range offset and get zeros
+//     from the range check without a branch or a memory request;
+//   * the side-byte word stays a raw SGPR until the block is decoded;
+//   * NB register buffers of U k-tiles (template), the patch table is requested FIRST (oldest in the queue).
+// Host side: needs floor((K / 32) / WAVES) >= NB * U (pick_default falls back to gemv_kernel otherwise: tiny models).
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+template <int NT, int EPI, int WAVES, int U, int RH, bool CW, int NB>
+__global__ __launch_bounds__(WAVES * 64) void gemv_pipe_kernel(GemvArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[WAVES][NT][RH][64][4];
+  constexpr int SW = WAVES < 4 ? WAVES : 4;
+  __shared__ float sh_ps[SW][RH][64];
+  __shared__ uint16_t sh_patch[CW ? 256 : 1];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int KT = a.K >> 5;
+  const int ntile0 = blockIdx.x * NT;
+  ScaleRegs<RH> sc;
+  scale_load<SW, RH>(a, sc, w, lane);                                // first loads of the wave (nothing waits for them until the end)
+  uint16_t pv = 0;
+  if constexpr (CW) {
+    if (tid < 256) pv = a.patch[(size_t)blockIdx.x * 256 + tid];      // ahead of the weight loads: its wait leaves them in flight
+  }
+  const int nk = (KT - w + WAVES - 1) / WAVES;                       // k-tiles kt = w + WAVES * i, i < nk (host: nk >= NB * U)
+  const int nfull = nk / U;                                          // steps whose U k-tiles all exist
+  // activation fragments: buffer loads, lanes of missing rows out of range (-> zeros, no request)
+  const uint32_t x_bytes = a.x_xf ? (uint32_t)(((a.M + 15) >> 4) * 16) * (uint32_t)a.K * 2u : (uint32_t)(a.M - 1) * (uint32_t)a.ldx * 2u + (uint32_t)a.K * 2u;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.X, 0, (a.dbg & 1) ? 0 : (int)x_bytes, 0x00020000);
+  uint32_t xoff[RH];
+  {
+    const int g = lane >> 4, r16 = lane & 15;
+#pragma unroll
+    for (int hf = 0; hf < RH; ++hf) {
+      const int row = r16 + 16 * hf;
+      const uint32_t o = a.x_xf ? ((uint32_t)hf * 16u * (uint32_t)a.K + (uint32_t)(g * 16 + r16) * 8u) * 2u
+                                : ((uint32_t)row * (uint32_t)a.ldx + (uint32_t)g * 8u) * 2u;
+      xoff[hf] = row < a.M ? o : 0x80000000u;
+    }
+  }
+  const uint32_t xstepB = a.x_xf ? 1024u : 64u;                       // bytes between the fragments of consecutive k-tiles
+  const size_t blk0 = (size_t)ntile0 * KT;
+  // weights through a descriptor over this unit's blocks (offsets stay inside the unit: 32 bits are plenty)
+  const uint32_t w_bytes = (uint32_t)NT * (uint32_t)KT * (CW ? 768u : 1024u);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      CW ? (void*)(a.Wc + blk0 * 768) : (void*)(a.Wp + blk0 * 512), 0, (a.dbg & 2) ? 0 : (int)w_bytes, 0x00020000);
+  const int wlane = lane * (CW ? 12 : 16);
+  // CW: the side bytes of ALL this wave's blocks, one byte load per n-tile (lane i <- k-tile index i; host: nk <= 64), read
+  // back with v_readlane at decode time. (r2 fetched each block's byte by s_load next to its weight load: scalar loads
+  // return out of order, so every use drained lgkmcnt -- a scalar-cache round trip per block in the wave's critical path.)
+  uint32_t ev[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    ev[nt] = 0u;
+    if constexpr (CW) {
+      if (lane < nk) ev[nt] = a.emin[blk0 + (size_t)nt * KT + w + lane * WAVES];
+    }
+  }
+
+  WFrag<CW> wb[NB][U][NT];
+  u32x4 xb[NB][U][RH];
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        if constexpr (CW) wb[b][u][nt].r.c = u32x3{0u, 0u, 0u};
+        else wb[b][u][nt].v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int hf = 0; hf < RH; ++hf) xb[b][u][hf] = u32x4{0u, 0u, 0u, 0u};
+    }
+  auto load1 = [&](WFrag<CW> (&wd)[NT], u32x4 (&xd)[RH], int i) {   // k-tile index i of this wave
+    const int kt = w + i * WAVES;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if constexpr (CW) {
+        wd[nt].r.c = __builtin_bit_cast(u32x3, __builtin_amdgcn_raw_buffer_load_b96(wrs, wlane, (nt * KT + kt) * 768, 2));
+      } else {
+        wd[nt].v = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlane, (nt * KT + kt) * 1024, 2));
+      }
+    }
+#pragma unroll
+    for (int hf = 0; hf < RH; ++hf)
+      xd[hf] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)xoff[hf], (int)((uint32_t)kt * xstepB), 0));
+  };
+  f32x4 acc[NT][RH];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int hf = 0; hf < RH; ++hf) acc[nt][hf] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mul1 = [&](WFrag<CW> (&ws)[NT], u32x4 (&xs)[RH], int i) {
+    bf16x8 wf[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if constexpr (CW) wf[nt] = cw_decode(ws[nt].r, (uint32_t)__builtin_amdgcn_readlane((int)ev[nt], i), sh_patch);
+      else wf[nt] = ws[nt].v;
+    }
+#pragma unroll
+    for (int hf = 0; hf < RH; ++hf) {
+      const bf16x8 xf = __builtin_bit_cast(bf16x8, xs[hf]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt][hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf, acc[nt][hf], 0, 0, 0);
+    }
+  };
+
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) load1(wb[b][u], xb[b][u], b * U + u);
+    __builtin_amdgcn_sched_barrier(0);                                // issue order = the loop's (the counted waits assume it)
+  }
+  if constexpr (CW) {
+    if (tid < 256) sh_patch[tid] = pv;
+    __syncthreads();
+  }
+  int s = 0;
+  for (; s + 2 * NB <= nfull; s += NB) {                              // steps s .. s + 2 NB - 1 are full: no branch around any load
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) mul1(wb[b][u], xb[b][u], (s + b) * U + u);
+#pragma unroll
+      for (int u = 0; u < U; ++u) load1(wb[b][u], xb[b][u], (s + NB + b) * U + u);
+      __builtin_amdgcn_sched_barrier(0);                              // keep the next buffer's decode behind these loads' issue
+    }
+  }
+  // the ragged end: buffers hold the full steps s .. s + NB - 1; at most NB more steps, some k-tiles missing
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) mul1(wb[b][u], xb[b][u], (s + b) * U + u);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if ((s + NB + b) * U + u < nk) load1(wb[b][u], xb[b][u], (s + NB + b) * U + u);
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if ((s + NB + b) * U + u < nk) mul1(wb[b][u], xb[b][u], (s + NB + b) * U + u);
+
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int hf = 0; hf < RH; ++hf) *(f32x4*)&red[w][nt][hf][lane][0] = acc[nt][hf];
+  scale_park<SW, RH>(a, sc, sh_ps, w, lane);
+  __syncthreads();
+  if constexpr (EPI == EPI_SWIGLU || EPI == EPI_ROPE_KV) {
+    if (w == 0) epilogue_pair<NT, EPI, WAVES, RH>(a, red, blockIdx.x, lane, sh_ps);
+    if constexpr (NT == 3) {
+      if (w == (WAVES > 1 ? 1 : 0)) epilogue_vtile<NT, WAVES, RH>(a, red, blockIdx.x, lane, sh_ps);
+    }
+  } else {
+    if (w < NT) epilogue_tile<NT, EPI, WAVES, RH>(a, red, w, ntile0 + w, lane, sh_ps);
+  }
+}
+
 // Persistent form: a fixed grid (<= one workgroup per CU), each workgroup walks units u = blockIdx.x, + gridDim.x, ...
 // (unit = NT n-tiles) and every wave treats its k-tiles of ALL its units as ONE stream of loads: the register ping-pong
 // keeps running across unit boundaries, so the memory pipe of a CU never drains while a unit is reduced and written.
@@ -684,6 +850,34 @@ void go(const GemvArgs& a, int ntiles, hipStream_t s) {
   else go_rh<NT, EPI, WAVES, U, KMODE, 1>(a, ntiles, s);
 }
 
+// the pipelined one-unit kernel (gemv_pipe_kernel): same K split as go<NT, EPI, WAVES, *, 1>, so the same bits
+bool g_gemv_legacy = false;   // tests / tools: force the r2 kernels (launch_gemv_legacy)
+template <int WAVES, int U, int NB>
+bool pipe_ok(const GemvArgs& a) {
+  const int KT = a.K >> 5;
+  return !g_gemv_legacy && KT / WAVES >= NB * U && (KT + WAVES - 1) / WAVES <= 64 && (long)a.M * a.ldx * 2 < (1l << 31) &&
+         (long)((a.M + 15) / 16) * 16 * a.K * 2 < (1l << 31);
+}
+template <int NT, int EPI, int WAVES, int U, int RH, bool CW, int NB>
+void go_pipe_cw(const GemvArgs& a, int ntiles, hipStream_t s) {
+  if (a.ev_start)
+    hipExtLaunchKernelGGL((gemv_pipe_kernel<NT, EPI, WAVES, U, RH, CW, NB>), dim3(ntiles / NT), dim3(WAVES * 64), 0, s, (hipEvent_t)a.ev_start,
+                          (hipEvent_t)a.ev_stop, 0, a);
+  else
+    hipLaunchKernelGGL((gemv_pipe_kernel<NT, EPI, WAVES, U, RH, CW, NB>), dim3(ntiles / NT), dim3(WAVES * 64), 0, s, a);
+}
+template <int NT, int EPI, int WAVES, int U, int NB>
+void go_pipe(const GemvArgs& a, int ntiles, hipStream_t s) {
+  static_assert(WAVES >= 4, "the compressed stream needs 256 threads for the patch table");
+  if (a.M > 16) {
+    if (a.Wc) go_pipe_cw<NT, EPI, WAVES, U, 2, true, NB>(a, ntiles, s);
+    else go_pipe_cw<NT, EPI, WAVES, U, 2, false, NB>(a, ntiles, s);
+  } else {
+    if (a.Wc) go_pipe_cw<NT, EPI, WAVES, U, 1, true, NB>(a, ntiles, s);
+    else go_pipe_cw<NT, EPI, WAVES, U, 1, false, NB>(a, ntiles, s);
+  }
+}
+
 // Tuned on MI355X with tools/decode_bench (M = 8, LLaMA-7B shapes). Shallow load queues win everywhere (deeper unrolls
 // oversubscribe the memory system: -10..-25 %); about 8 MiB in flight over the chip is the sweet spot.
 //   o, down (residual epilogue, N = 4096: 256 units)   one unit per workgroup, K split 16 ways
@@ -705,10 +899,18 @@ hipError_t pick_default(const GemvArgs& a, int ntiles, hipStream_t s) {
   // Compressed weights (a.Wc): the same K split as the bf16 stream (so the same bits), but 768-B blocks need more blocks in
   // flight for the same bytes in flight: two k-tiles per buffer on the short-K one-unit kernels, two workgroups per CU on lm_head.
   if (units <= 256 || KT < 12) {
-    if (units <= 256 && EPI == EPI_ROPE_KV && KT >= 16) go<NT, EPI, 8, 2, 1>(a, ntiles, s);   // 3-tile units: 18.1 vs 18.4 us
-    else if (units <= 256 && a.Wc && KT >= 64 && KT <= 128) go<NT, EPI, 16, 2, 1>(a, ntiles, s);   // o_proj compressed: 7.1 vs 7.4 us
-    else if (units <= 256) go<NT, EPI, 16, 1, 1>(a, ntiles, s);
-    else go<NT, EPI, 4, 2, 1>(a, ntiles, s);
+    // r3: the pipelined kernel wherever the k-run is long enough (pipe_ok), on the r2 kernels' K split (8 waves for the
+    // 3-tile q/k/v units, 16 otherwise): identical bits, counted waits.
+    if (units <= 256 && EPI == EPI_ROPE_KV && KT >= 16) {
+      if (pipe_ok<8, 2, 2>(a)) go_pipe<NT, EPI, 8, 2, 2>(a, ntiles, s);
+      else go<NT, EPI, 8, 2, 1>(a, ntiles, s);   // 3-tile units: 18.1 vs 18.4 us
+    } else if (units <= 256 && a.Wc && KT >= 64 && KT <= 128) {
+      if (pipe_ok<16, 2, 2>(a)) go_pipe<NT, EPI, 16, 2, 2>(a, ntiles, s);
+      else go<NT, EPI, 16, 2, 1>(a, ntiles, s);   // o_proj compressed: 7.1 vs 7.4 us
+    } else if (units <= 256) {
+      if (pipe_ok<16, 1, 2>(a)) go_pipe<NT, EPI, 16, 1, 2>(a, ntiles, s);
+      else go<NT, EPI, 16, 1, 1>(a, ntiles, s);
+    } else go<NT, EPI, 4, 2, 1>(a, ntiles, s);
   } else if constexpr (EPI == EPI_ROPE_KV) {
     go_pers<NT, EPI, 4, 1>(a, ntiles, units, s);
   } else if constexpr (EPI == EPI_SWIGLU) {
@@ -731,12 +933,6 @@ hipError_t pick(const GemvArgs& a, int ntiles, int variant, hipStream_t s) {
   if (ntiles % NT) return hipErrorInvalidValue;
   switch (variant) {
 #ifdef GEMV_ALL_VARIANTS   // tools/decode_bench: variant = 1 + wi*3 + ui, W in {1,2,4,8,16}, U in {2,4,8}, KMODE 1
-    case 1: go<NT, EPI, 1, 2, 1>(a, ntiles, s); break;
-    case 2: go<NT, EPI, 1, 4, 1>(a, ntiles, s); break;
-    case 3: go<NT, EPI, 1, 8, 1>(a, ntiles, s); break;
-    case 4: go<NT, EPI, 2, 2, 1>(a, ntiles, s); break;
-    case 5: go<NT, EPI, 2, 4, 1>(a, ntiles, s); break;
-    case 6: go<NT, EPI, 2, 8, 1>(a, ntiles, s); break;
     case 7: go<NT, EPI, 4, 2, 1>(a, ntiles, s); break;
     case 8: go<NT, EPI, 4, 4, 1>(a, ntiles, s); break;
     case 9: go<NT, EPI, 4, 8, 1>(a, ntiles, s); break;
@@ -746,6 +942,11 @@ hipError_t pick(const GemvArgs& a, int ntiles, int variant, hipStream_t s) {
     case 13: go<NT, EPI, 16, 2, 1>(a, ntiles, s); break;
     case 14: go<NT, EPI, 16, 4, 1>(a, ntiles, s); break;
     case 15: go<NT, EPI, 16, 1, 1>(a, ntiles, s); break;
+    // pipelined kernel: 40 + 6 * (W == 16) + 3 * (U - 1) + (NB - 2), W in {8, 16}, U in {1, 2}, NB in {2, 3, 4}
+#define PIPE_CASE(v, W, U_, NB_) case v: if constexpr (EPI == EPI_RESIDUAL || EPI == EPI_ROPE_KV) { if (NT == 2 || !pipe_ok<W, U_, NB_>(a)) return hipErrorInvalidValue; go_pipe<NT, EPI, W, U_, NB_>(a, ntiles, s); break; } else return hipErrorInvalidValue;
+    PIPE_CASE(40, 8, 1, 2) PIPE_CASE(41, 8, 1, 3) PIPE_CASE(42, 8, 1, 4) PIPE_CASE(43, 8, 2, 2) PIPE_CASE(44, 8, 2, 3) PIPE_CASE(45, 8, 2, 4)
+    PIPE_CASE(46, 16, 1, 2) PIPE_CASE(47, 16, 1, 3) PIPE_CASE(48, 16, 1, 4) PIPE_CASE(49, 16, 2, 2) PIPE_CASE(50, 16, 2, 3) PIPE_CASE(51, 16, 2, 4)
+#undef PIPE_CASE
 #endif
     default:
       return pick_default<NT, EPI>(a, ntiles, s);
@@ -765,7 +966,7 @@ hipError_t launch_gemv_ex(const GemvArgs& a, int epi, int variant, hipStream_t s
     case EPI_NONE: return pick<1, EPI_NONE>(a, ntiles, variant, s);
     case EPI_GELU: return pick<1, EPI_GELU>(a, ntiles, variant, s);
 #ifdef GEMV_ALL_VARIANTS   // tools/decode_bench: variants 20 + v = two-tile units for the residual projections (128 workgroups at N = 4096)
-    case EPI_RESIDUAL: return variant >= 20 ? pick<2, EPI_RESIDUAL>(a, ntiles, variant - 20, s) : pick<1, EPI_RESIDUAL>(a, ntiles, variant, s);
+    case EPI_RESIDUAL: return variant >= 20 && variant < 40 ? pick<2, EPI_RESIDUAL>(a, ntiles, variant - 20, s) : pick<1, EPI_RESIDUAL>(a, ntiles, variant, s);
 #else
     case EPI_RESIDUAL: return pick<1, EPI_RESIDUAL>(a, ntiles, variant, s);
 #endif
@@ -808,6 +1009,8 @@ hipError_t launch_gemv_pers(const GemvArgs& a, int epi, int waves, int u, int gr
   return hipErrorInvalidValue;
 }
 #endif
+
+void gemv_force_legacy(int on) { g_gemv_legacy = on != 0; }
 
 hipError_t launch_gemv(const GemmArgs& g, int epi, hipStream_t s) {
   GemvArgs a = {};

@@ -66,8 +66,12 @@ struct GemvArgs {
   // optional (host side only): HIP events that bracket exactly this kernel's execution (hipExtLaunchKernelGGL start /
   // stop events = the dispatch's own timestamps, what rocprofv3's kernel trace reports), for orc_profile_read
   void* ev_start; void* ev_stop;
+  // tools/decode_bench only (gemv_pipe_kernel): timing experiments that keep the instruction stream and drop the memory requests --
+  // bit 0: the activation descriptor has zero records, bit 1: the weight descriptor has (results are garbage)
+  int dbg = 0;
 };
 hipError_t launch_gemv_ex(const GemvArgs& a, int epi, int variant, hipStream_t s);
+void gemv_force_legacy(int on);   // tests / tools: 1 = run the r2 kernels (branchy k-loop) instead of the pipelined ones; same bits
 // lossless 12-bit compression of a packed matrix for the decode GEMVs (gemv.hip): Wc N*K*3/2 bytes, emin N/16*K/32 bytes (+3 pad),
 // patch (N/16/nt_unit)*256 uint16, cnt N/16/nt_unit ints; *overflow_dev is set when a unit has more than 254 non-zero escapes (escaped zeros share two constant entries)
 int gemv_unit_tiles(int epi, int N);

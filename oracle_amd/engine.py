@@ -232,14 +232,15 @@ class Engine:
 def test_gemm(x, w, bias=None, residual=None, epilogue='none', use_gemv=False, kernel=None):
     """kernel: None (automatic), 'tile128' (register-staged 128^2), 'dma256' / 'dma128' (LDS-DMA, BM x 256 tiles of one
     height), 'mix<n>' (LDS-DMA, n 256-row m-tiles + 128-row tiles for the remaining rows in one launch).
-    use_gemv='cw': the decode GEMV on the lossless 12-bit copy of w (must equal use_gemv=True bit for bit)."""
+    use_gemv='cw': the decode GEMV on the lossless 12-bit copy of w (must equal use_gemv=True bit for bit);
+    'legacy' / 'legacy_cw': the same two on the r2 kernels (branchy k-loop) instead of the pipelined ones."""
     l = _lib.lib()
     m, k = x.shape
     n = w.shape[0]
     nout = n // 2 if epilogue == 'swiglu' else n
     out = torch.empty(m, nout, dtype=torch.float32 if epilogue == 'f32' else torch.bfloat16, device=x.device)
     _lib.check(l.orc_test_gemm(_ptr(x), m, k, _ptr(w), n, _ptr(bias), _ptr(residual), EPI[epilogue],
-                               5 if use_gemv == 'cw' else 1 if use_gemv else (100 + int(kernel[3:]) if isinstance(kernel, str) and kernel.startswith('mix') else {None: 0, 'tile128': 2, 'dma256': 3, 'dma128': 4}[kernel]),
+                               {'cw': 5, 'legacy': 6, 'legacy_cw': 7}[use_gemv] if isinstance(use_gemv, str) else 1 if use_gemv else (100 + int(kernel[3:]) if isinstance(kernel, str) and kernel.startswith('mix') else {None: 0, 'tile128': 2, 'dma256': 3, 'dma128': 4}[kernel]),
                                _ptr(out), _stream()), 'orc_test_gemm')
     return out
 

@@ -282,6 +282,26 @@ def test_compressed_weight_stream_is_bit_exact(epi, N, K, M):
         assert torch.equal(plain.view(torch.int32 if epi == 'f32' else torch.int16), packed.view(torch.int32 if epi == 'f32' else torch.int16))
 
 
+@pytest.mark.parametrize('M', [1, 8, 16, 17, 32])
+@pytest.mark.parametrize('epi,N,K', [('residual', 4096, 11008), ('residual', 4096, 4096), ('none', 12288, 4096), ('residual', 512, 1408),
+                                     ('none', 4096, 2048), ('residual', 1024, 768 * 4)])
+def test_pipelined_gemv_equals_r2_kernels(epi, N, K, M):
+    """r3 one-unit decode GEMVs (gemv_pipe_kernel: peeled k-loop with counted waits, activation fragments through a buffer
+    descriptor, side bytes by one vector load + v_readlane) against the r2 kernels they replace (same K split): every output
+    bit equal, on the bf16 stream and on the 12-bit stream, Gaussian and escape-heavy weights, ragged k-runs (K = 11008 -> 21 / 22
+    k-tiles per wave; K = 1408 -> 2 / 3: falls back to the r2 kernel; K = 3072 -> 6 per wave)."""
+    from oracle_amd import engine as E
+    d = _dev()
+    x = _rand((M, K), 61).to(d)
+    res = _rand((M, N), 63).to(d) if epi == 'residual' else None
+    for w in (_rand((N, K), 62, 0.02), _nasty_weights(N, K, 64)):
+        w = w.to(d)
+        for new, old in ((True, 'legacy'), ('cw', 'legacy_cw')):
+            a = E.test_gemm(x, w, None, res, epi, use_gemv=new)
+            b = E.test_gemm(x, w, None, res, epi, use_gemv=old)
+            assert torch.equal(a.view(torch.int16), b.view(torch.int16)), (new, old)
+
+
 def test_compressed_weight_stream_refuses_more_than_256_escapes_per_unit():
     """A unit (16 rows x K of a one-tile kernel) whose blocks need more than 254 non-zero patch entries cannot be compressed: the hook
     reports it (the engine then keeps that matrix in bf16, engine.hip compress_for_decode)."""

@@ -127,6 +127,7 @@ int main(int argc, char** argv) {
   printf("M=%d ctx=%d  (us per launch incl. ~1.5us boundary; GB/s = algorithmic weight bytes / time)\n", M, ctx);
   // ---- read ceiling
   for (size_t mb : {33, 90, 100, 180}) {
+    if (getenv("DBG_EXP")) break;
     const size_t bytes = mb << 20;
     for (int grid : {256, 512, 1024, 2048}) {
       float us = time_it([&](int i) {
@@ -145,8 +146,11 @@ int main(int argc, char** argv) {
       {"head f32       ", 32000, d, EPI_F32},
   };
   for (const Shape& sh : shapes) {
+    if (getenv("DBG_EXP")) break;
     const size_t wbytes = (size_t)sh.N * sh.K * 2;
-    for (int variant = 0; variant <= 15; ++variant) {
+    for (int variant = 0; variant <= 51; ++variant) {
+      if (variant > 15 && variant < 40) continue;                    // 40..51: pipelined kernel (W, U, NB)
+      if (getenv("QUICK") && variant != 0 && variant < 40) continue;
       GemvArgs a = {};
       a.X = X; a.ldx = sh.K; a.bias = nullptr; a.R = R; a.ldr = sh.N; a.C = Y;
       a.ldc = sh.epi == EPI_SWIGLU ? sh.N / 2 : (sh.epi == EPI_ROPE_KV ? d : sh.N);
@@ -164,8 +168,46 @@ int main(int argc, char** argv) {
       if (err != hipSuccess) { printf("%s v%d : %s\n", sh.name, variant, hipGetErrorString(err)); (void)hipGetLastError(); continue; }
       const int vi = variant - 1;
       if (variant == 0) printf("%s default    : %7.2f us  %7.1f GB/s\n", sh.name, us, wbytes / us * 1e-3);
+      else if (variant >= 40) printf("%s pipe W%-2d U%d NB%d : %7.2f us  %7.1f GB/s\n", sh.name, variant >= 46 ? 16 : 8, ((variant - 40) % 6) / 3 + 1, (variant - 40) % 3 + 2, us, wbytes / us * 1e-3);
       else printf("%s W%-2d U%d    : %7.2f us  %7.1f GB/s\n", sh.name, 1 << (vi / 3), variant == 15 ? 1 : 2 << (vi % 3), us, wbytes / us * 1e-3);
     }
+  }
+  // ---- what bounds the one-unit kernels? the same launch with the activation requests and / or the weight requests dropped by the
+  // descriptors' range check (instruction stream, waits and epilogue unchanged)
+  if (getenv("DBG_EXP")) {
+    uint8_t* emin;
+    uint16_t* patch;
+    CK(hipMalloc((void**)&emin, (size_t)8 << 20));
+    CK(hipMemset(emin, 56, (size_t)8 << 20));
+    CK(hipMalloc((void**)&patch, (size_t)4096 * 256 * 2));
+    CK(hipMemset(patch, 0, (size_t)4096 * 256 * 2));
+    for (const Shape& sh : {shapes[0], shapes[1], shapes[3]}) {
+      const size_t wbytes = (size_t)sh.N * sh.K * 2;
+      GemvArgs a = {};
+      a.X = X; a.ldx = sh.K; a.bias = nullptr; a.R = R; a.ldr = sh.N; a.C = Y;
+      a.ldc = sh.epi == EPI_ROPE_KV ? d : sh.N;
+      a.M = M; a.N = sh.N; a.K = sh.K; a.Nvalid = sh.N;
+      a.H = H; a.kbeg = ints + 16; a.cur_len = ints; a.cos_tab = cosb; a.sin_tab = sinb;
+      a.maxpos = 4096; a.Kc = Kc; a.Vc = Vc; a.c_bs = (long)H * Tmax * 128; a.c_hs = (long)Tmax * 128;
+      a.ssq_out = ssq; a.x_xf = 1; a.c_xf = 1;
+      a.emin = emin; a.patch = patch;
+      for (int cw = 0; cw < 2; ++cw)
+        for (int dbg = 0; dbg < 4; ++dbg)
+          for (int rows : {1, 8, 16}) {
+            a.dbg = dbg; a.M = rows;
+            hipError_t err = hipSuccess;
+            float us = time_it([&](int i) {
+              const size_t off = (((size_t)i * wbytes) % (pool_bytes - wbytes)) & ~(size_t)1023;
+              a.Wp = (const bf16_t*)((char*)pool + off);
+              a.Wc = cw ? (const uint8_t*)pool + off : nullptr;
+              hipError_t e = launch_gemv_ex(a, sh.epi, 0, s);
+              if (e != hipSuccess) err = e;
+            });
+            printf("%s %s rows %2d %s%s : %7.2f us%s\n", sh.name, cw ? "compressed" : "plain     ", rows, (dbg & 1) ? "no-x " : "     ",
+                   (dbg & 2) ? "no-w " : "     ", us, err != hipSuccess ? "  LAUNCH ERROR" : "");
+          }
+    }
+    return 0;
   }
   // ---- compressed weight stream (12-bit blocks, gemv.hip CW kernels): timing on arbitrary compressed bytes, no escapes
   if (getenv("CW_EXP")) {
@@ -198,8 +240,35 @@ int main(int argc, char** argv) {
         printf("%s %s : %7.2f us  (%5.1f MB streamed, %7.1f GB/s physical)\n", sh.name, cw ? "compressed" : "plain     ", us,
                (cw ? cbytes : wbytes) * 1e-6, (cw ? cbytes : wbytes) / us * 1e-3);
       }
-      for (int variant : {7, 8, 10, 11, 13, 14, 15, 30, 31, 33, 34, 35}) {   // one unit per workgroup: W in {4, 8, 16}, U in {2, 4} (15: W16 U1); 20 + v: two-tile units
-        if (variant >= 20 && sh.epi != EPI_RESIDUAL) continue;
+      {   // the r2 kernels (branchy k-loop) on the same compressed bytes
+        gemv_force_legacy(1);
+        hipError_t err = hipSuccess;
+        float us = time_it([&](int i) {
+          const size_t off = (((size_t)i * wbytes) % (pool_bytes - wbytes)) & ~(size_t)1023;
+          a.Wp = (const bf16_t*)((char*)pool + off);
+          a.Wc = (const uint8_t*)pool + off;
+          hipError_t e = launch_gemv_ex(a, sh.epi, 0, s);
+          if (e != hipSuccess) err = e;
+        });
+        gemv_force_legacy(0);
+        printf("%s compressed r2 kernel : %7.2f us%s\n", sh.name, us, err != hipSuccess ? "  LAUNCH ERROR" : "");
+      }
+      for (int variant : {7, 8, 10, 11, 13, 14, 15, 30, 31, 33, 34, 35, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51}) {   // one unit per workgroup: W in {4, 8, 16}, U in {2, 4} (15: W16 U1); 20 + v: two-tile units; 40+: pipelined
+        if (variant >= 20 && variant < 40 && sh.epi != EPI_RESIDUAL) continue;
+        if (getenv("QUICK") && variant < 40) continue;
+        if (variant >= 40) {
+          hipError_t err = hipSuccess;
+          float us = time_it([&](int i) {
+            const size_t off = (((size_t)i * wbytes) % (pool_bytes - wbytes)) & ~(size_t)1023;
+            a.Wp = (const bf16_t*)((char*)pool + off);
+            a.Wc = (const uint8_t*)pool + off;
+            hipError_t e = launch_gemv_ex(a, sh.epi, variant, s);
+            if (e != hipSuccess) err = e;
+          });
+          if (err != hipSuccess) { (void)hipGetLastError(); continue; }
+          printf("%s compressed pipe W%-2d U%d NB%d : %7.2f us   %7.1f GB/s physical\n", sh.name, variant >= 46 ? 16 : 8, ((variant - 40) % 6) / 3 + 1, (variant - 40) % 3 + 2, us, cbytes / us * 1e-3);
+          continue;
+        }
         hipError_t err = hipSuccess;
         float us = time_it([&](int i) {
           const size_t off = (((size_t)i * wbytes) % (pool_bytes - wbytes)) & ~(size_t)1023;
@@ -251,6 +320,7 @@ int main(int argc, char** argv) {
         }
         CK(hipFree(gw)); CK(hipFree(gc)); CK(hipFree(ge)); CK(hipFree(gp)); CK(hipFree(cnt));
       }
+      if (getenv("QUICK")) continue;
       // persistent sweep on the compressed stream
       const int units = sh.N / 16 / (sh.epi == EPI_RESIDUAL ? 1 : (sh.epi == EPI_ROPE_KV ? 3 : 2));
       for (int waves : {8, 12, 16})
@@ -351,7 +421,8 @@ int main(int argc, char** argv) {
     a.Q = X; a.q_bs = d; a.c_bs = (long)H * Tmax * 128; a.c_hs = (long)Tmax * 128; a.O = Y; a.o_bs = d;
     a.part = part; a.kbeg = ints + 16; a.cur_len = ints; a.B = M; a.H = H; a.scale = 0.0883883f;
     const size_t bytes = (size_t)M * H * ctx * 512;
-    for (int variant = 0; variant <= 11; ++variant) {
+    for (int variant : {0, 100, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18}) {   // 0 = default (pipelined 16 x 1), 100 = r2 kernel, 12..18 pipelined (waves, U)
+      if (getenv("QUICK") && variant >= 1 && variant <= 11) continue;
       float us = time_it([&](int i) {
         a.Kc = Kc + (size_t)(i % 8) * kv_elems;
         a.Vc = Vc + (size_t)(i % 8) * kv_elems;
