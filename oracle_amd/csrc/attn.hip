@@ -388,9 +388,16 @@ __global__ __launch_bounds__(WAVES * 64) void decode_attn_pipe_kernel(DecodeAttn
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kq = lane >> 4, c = lane & 15;
   const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z, nsplit = gridDim.z;
+#ifdef GEMV_ALL_VARIANTS
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+  if (a.dbg_ts) ts0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int sl = a.map.slot[b];
   const int len = sl < 0 ? 1 : a.cur_len[sl];
   const int kb = sl < 0 ? 0 : a.kbeg[sl];
+#ifdef GEMV_ALL_VARIANTS
+  if (a.dbg_ts) { asm volatile("" :: "s"(len), "s"(kb)); ts1 = __builtin_amdgcn_s_memrealtime(); }
+#endif
   if (sl < 0 || (a.unfinished && !a.unfinished[sl])) {   // inactive or finished row (its tokens are pad): no cache read at all
     if (tid < 128) {
       if (nsplit == 1) {
@@ -467,6 +474,13 @@ __global__ __launch_bounds__(WAVES * 64) void decode_attn_pipe_kernel(DecodeAttn
       base += U * STEP;
     }
   }
+#ifdef GEMV_ALL_VARIANTS
+  if (a.dbg_ts) {
+    ts2 = __builtin_amdgcn_s_memrealtime();
+    const size_t nb = (size_t)gridDim.x * gridDim.y, blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    if (lane == 0) a.dbg_ts[nb * 4 + blk * 16 + w] = ts2 - ts0;
+  }
+#endif
   // merge the 4 key slots of the wave
 #pragma unroll
   for (int off = 16; off <= 32; off <<= 1) {
@@ -506,6 +520,16 @@ __global__ __launch_bounds__(WAVES * 64) void decode_attn_pipe_kernel(DecodeAttn
       pp[2 + tid] = av;
     }
   }
+#ifdef GEMV_ALL_VARIANTS
+  if (a.dbg_ts && w == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long ts3 = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) {
+      unsigned long long* o = a.dbg_ts + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
+      o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = ts3;
+    }
+  }
+#endif
 }
 
 __global__ __launch_bounds__(128) void decode_attn_combine_kernel(DecodeAttnArgs a, int nsplit) {
@@ -565,8 +589,10 @@ hipError_t launch_decode_attention(const DecodeAttnArgs& a, hipStream_t s, int v
       case 10: hipLaunchKernelGGL((decode_attn_kernel<2, 4>), dim3(a.H, a.B, 1), dim3(128), 0, s, a); break;
       case 11: hipLaunchKernelGGL((decode_attn_kernel<2, 8>), dim3(a.H, a.B, 1), dim3(128), 0, s, a); break;
 #endif
-      // 16 waves, 4-key steps, the next step in flight while this one is computed (r3: decode_attn_pipe_kernel)
-      default: hipLaunchKernelGGL((decode_attn_pipe_kernel<16, 1>), dim3(a.H, a.B, 1), dim3(1024), 0, s, a); break;
+      // r3: 8 waves, 4-key steps, the next step in flight while this one is computed (decode_attn_pipe_kernel). Per-wave stamps
+      // (tools/decode_bench TS_EXP): the waves that share a SIMD finish in dispatch order -- 16 waves: 16.3 / 17.3 / 17.5 / 18.8 us after
+      // entry, 8 waves: 14.7 / 15.3 -- and the cross-wave merge is half as long; the key loop itself streams at 6.4-6.9 TB/s either way.
+      default: hipLaunchKernelGGL((decode_attn_pipe_kernel<8, 1>), dim3(a.H, a.B, 1), dim3(512), 0, s, a); break;
     }
   } else {
     // few (row, head) pairs: split every key range so that about one workgroup per CU streams the cache

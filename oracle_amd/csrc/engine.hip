@@ -108,6 +108,9 @@ struct orc_engine {
   float* w_logits = nullptr;
   float* w_part = nullptr;
   float* d_ssq = nullptr;   // [16][d_model/16] per-n-tile sums of squares of the decode hidden state
+  // per decode ROW, refreshed by the token gather of every step (kernels.h RowMetaArgs): {slot, cached keys, left pad, unfinished},
+  // and the rotary table rows of the row's position -- what the q/k/v epilogue otherwise chases through three dependent loads
+  int* d_rowmeta = nullptr; bf16_t* d_rowcos = nullptr; bf16_t* d_rowsin = nullptr;
   bf16_t* d_hxf = nullptr;   // decode hidden rows in the fragment-ordered layout (input of the norm-folded projections)
   bf16_t *d_h = nullptr, *d_xn = nullptr, *d_qkv = nullptr, *d_att = nullptr, *d_mlp = nullptr;   // decode (<=16 rows)
   int *dev_ints = nullptr;   // [0]=step [2]=n_unfinished, then per-row arrays of 16 (DI_* offsets), then the token buffer
@@ -517,6 +520,9 @@ extern "C" int orc_engine_finalize(orc_engine* e) {
     ORCCHK(e->alloc((void**)&e->w_logits, (size_t)kMaxRows * c.vocab * 4));
     ORCCHK(e->alloc((void**)&e->w_part, (size_t)kMaxRows * c.n_heads * DECODE_NSPLIT * 130 * 4));
     ORCCHK(e->alloc((void**)&e->d_ssq, (size_t)kMaxRows * (c.d_model / 16) * 4));
+    ORCCHK(e->alloc((void**)&e->d_rowmeta, (size_t)kMaxRows * 4 * 4));
+    ORCCHK(e->alloc((void**)&e->d_rowcos, (size_t)kMaxRows * 64 * 2));
+    ORCCHK(e->alloc((void**)&e->d_rowsin, (size_t)kMaxRows * 64 * 2));
     ORCCHK(e->alloc((void**)&e->d_h, (size_t)kMaxRows * c.d_model * 2));
     ORCCHK(e->alloc((void**)&e->d_hxf, (size_t)kMaxRows * c.d_model * 2));
     HIPCHK(hipMemset(e->d_hxf, 0, (size_t)kMaxRows * c.d_model * 2));
@@ -708,6 +714,7 @@ static int gemv_ex(orc_engine* e, const bf16_t* X, int ldx, const Packed& W, con
   a.H = c.n_heads; a.kbeg = e->d_kbeg; a.cur_len = e->d_curlen; a.cos_tab = e->cos_tab; a.sin_tab = e->sin_tab;
   a.maxpos = e->maxpos; a.Kc = kc; a.Vc = vc; a.c_bs = e->c_bs; a.c_hs = e->c_hs;
   a.ssq_out = ssq_out;
+  if (epi == EPI_ROPE_KV) { a.row_meta = e->d_rowmeta; a.row_cos = e->d_rowcos; a.row_sin = e->d_rowsin; }   // of this step (decode_one)
   hipError_t err = launch_gemv_ex(a, epi, 0, s);
   if (err != hipSuccess) return fail("launch_gemv_ex", hipGetErrorString(err));
   return 0;
@@ -893,7 +900,10 @@ static int decode_one(orc_engine* e, const int32_t* forced, float* logits_out, h
   const orc_config& c = e->c;
   const int B = e->cur_batch;
   ++e->steps_issued;
-  HIPCHK(launch_embed_tokens(forced, e->d_next, e->row_map, e->embed, e->d_h, B, c.d_model, c.vocab, e->d_ssq, c.d_model / 16, s, e->d_hxf));
+  RowMetaArgs rm;
+  rm.cur_len = e->d_curlen; rm.kbeg = e->d_kbeg; rm.unfinished = e->d_unf; rm.cos_tab = e->cos_tab; rm.sin_tab = e->sin_tab;
+  rm.maxpos = e->maxpos; rm.row_meta = e->d_rowmeta; rm.row_cos = e->d_rowcos; rm.row_sin = e->d_rowsin;
+  HIPCHK(launch_embed_tokens(forced, e->d_next, e->row_map, e->embed, e->d_h, B, c.d_model, c.vocab, e->d_ssq, c.d_model / 16, s, e->d_hxf, &rm));
   // free-running: finished rows freeze (their tokens are pad, their cache is not read or grown); teacher forcing: every
   // row advances with the forced token whatever the sampler thinks
   ORCCHK(llama_decode_layers(e, B, s, forced == nullptr));

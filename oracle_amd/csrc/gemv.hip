@@ -198,12 +198,39 @@ __device__ __forceinline__ float scale_of_row(const GemvArgs& a, const float (*s
   return rsqrtf(s / (float)a.norm_d + a.norm_eps);
 }
 
+// Operands of the q/k/v epilogue that do not depend on this launch's arithmetic (slot, cached length, rotary row): r2 loaded
+// them in the epilogue as a chain of three dependent loads (slot -> length -> cos / sin) at the very end of the kernel, with
+// the memory system idle (~2 us of the launch: tools/decode_bench TS_EXP). The token gather of a decode step now leaves them per
+// ROW (GemvArgs::row_meta / row_cos / row_sin, misc.hip embed_tokens_kernel) and the pipelined kernel requests them at entry: one
+// level of loads, nothing waits for them until the epilogue.
+template <int RH> struct RopePre { int sl[RH]; int len[RH]; u32x2 cv[RH], sv[RH]; };
+template <int RH>
+__device__ __forceinline__ void rope_pre_load(const GemvArgs& a, RopePre<RH>& p, int pair, int lane, bool want_tab) {
+  const int g = lane >> 4;
+#pragma unroll
+  for (int hf = 0; hf < RH; ++hf) {
+    const int b = (lane & 15) + 16 * hf;
+    p.sl[hf] = -1; p.len[hf] = 1;
+    p.cv[hf] = u32x2{0u, 0u}; p.sv[hf] = u32x2{0u, 0u};
+    if (b >= a.M) continue;
+    const u32x2 m = *(const u32x2*)(a.row_meta + 4 * b);               // {slot, cached keys incl. this token, left pad, unfinished}
+    p.sl[hf] = (int)m[0]; p.len[hf] = (int)m[1];
+    if (want_tab) {
+      const int d = (pair & 3) * 16 + 4 * g;
+      p.cv[hf] = *(const u32x2*)(a.row_cos + b * 64 + d);
+      p.sv[hf] = *(const u32x2*)(a.row_sin + b * 64 + d);
+    }
+  }
+}
+
 // ---- epilogues. `red` = this unit's partial D tiles [WAVES][NT][RH][64 lanes][4]; a lane holds column b = lane & 15 (+ 16 per
 // row half) and rows n = 16 * tile + 4 * (lane >> 4) + r of a D tile.
 // Paired epilogues (one wave): tile 0 and tile 1 of the unit are partners (gate / up, or rotary halves).
-template <int NT, int EPI, int WAVES, int RH>
+// PRE: the rotary / cache operands were requested at kernel entry (`pre`, by reference so that it stays in registers: a nullable
+// pointer sent the whole argument block to scratch memory); otherwise the epilogue loads them itself.
+template <int NT, int EPI, int WAVES, int RH, bool PRE = false>
 __device__ __forceinline__ void epilogue_pair(const GemvArgs& a, const float (*red)[NT][RH][64][4], int pair, int lane,
-                                              const float (*sh_ps)[RH][64]) {
+                                              const float (*sh_ps)[RH][64], const RopePre<RH>& pre = RopePre<RH>()) {
   static_assert(NT == 2 || (NT == 3 && EPI == EPI_ROPE_KV), "paired tiles (+ one V tile for the q/k/v projection)");
   constexpr int SW = WAVES < 4 ? WAVES : 4;
   const int g = lane >> 4;
@@ -238,18 +265,28 @@ __device__ __forceinline__ void epilogue_pair(const GemvArgs& a, const float (*r
       // rows were packed so that tile 0 holds head dims [d0, d0+16) and tile 1 their rotary partners [d0+64, ...)
       const int hs = pair >> 2, d = (pair & 3) * 16 + 4 * g;
       const int sec = hs / a.H, h = hs % a.H;
-      const int sl = a.map.slot[b];
+      const int sl = PRE ? pre.sl[hf] : a.map.slot[b];
       if (sl < 0) continue;                                            // inactive decode row
-      const int len = a.cur_len[sl];
-      const int pos_raw = len - 1 - a.kbeg[sl];
-      const int pos = pos_raw < 0 ? 0 : (pos_raw >= a.maxpos ? a.maxpos - 1 : pos_raw);
+      int len, pos = 0;
+      if constexpr (PRE) {
+        len = pre.len[hf];
+      } else {
+        len = a.cur_len[sl];
+        const int pos_raw = len - 1 - a.kbeg[sl];
+        pos = pos_raw < 0 ? 0 : (pos_raw >= a.maxpos ? a.maxpos - 1 : pos_raw);
+      }
       const int slot = len - 1;
       float lo[4], hi[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) { lo[r] = rbf(t0[r]); hi[r] = rbf(t1[r]); }
       if (sec < 2) {
-        const u32x2 cv = *(const u32x2*)(a.cos_tab + (size_t)pos * 64 + d);
-        const u32x2 sv = *(const u32x2*)(a.sin_tab + (size_t)pos * 64 + d);
+        u32x2 cv, sv;
+        if constexpr (PRE) {
+          cv = pre.cv[hf]; sv = pre.sv[hf];
+        } else {
+          cv = *(const u32x2*)(a.cos_tab + (size_t)pos * 64 + d);
+          sv = *(const u32x2*)(a.sin_tab + (size_t)pos * 64 + d);
+        }
         const float c[4] = {lo_bf(cv[0]), hi_bf(cv[0]), lo_bf(cv[1]), hi_bf(cv[1])};
         const float s[4] = {lo_bf(sv[0]), hi_bf(sv[0]), lo_bf(sv[1]), hi_bf(sv[1])};
         float ol[4], oh[4];
@@ -276,9 +313,9 @@ __device__ __forceinline__ void epilogue_pair(const GemvArgs& a, const float (*r
 
 // Third tile of a q/k/v unit: 16 dims of the V projection (no rotary) -> V cache. Unit u carries V tile u, i.e. dims
 // [16 * (u % 8), +16) of head u / 8.
-template <int NT, int WAVES, int RH>
+template <int NT, int WAVES, int RH, bool PRE = false>
 __device__ __forceinline__ void epilogue_vtile(const GemvArgs& a, const float (*red)[NT][RH][64][4], int unit, int lane,
-                                               const float (*sh_ps)[RH][64]) {
+                                               const float (*sh_ps)[RH][64], const RopePre<RH>& pre = RopePre<RH>()) {
   constexpr int SW = WAVES < 4 ? WAVES : 4;
   const int g = lane >> 4;
 #pragma unroll
@@ -289,19 +326,23 @@ __device__ __forceinline__ void epilogue_vtile(const GemvArgs& a, const float (*
     for (int i = 0; i < WAVES; ++i) t += *(const f32x4*)&red[i][2][hf][lane][0];
     if (b >= a.M) continue;
     if (a.ssq_in) t *= scale_of_row<SW, RH>(a, sh_ps, hf, lane & 15);
-    const int sl = a.map.slot[b];
+    const int sl = PRE ? pre.sl[hf] : a.map.slot[b];
     if (sl < 0) continue;
     const int h = unit >> 3, d = (unit & 7) * 16 + 4 * g;
-    const int slot = a.cur_len[sl] - 1;
+    int slot;
+    if constexpr (PRE) slot = pre.len[hf] - 1;
+    else slot = a.cur_len[sl] - 1;
     u32x2 st = {pack2(t[0], t[1]), pack2(t[2], t[3])};
     *(u32x2*)(a.Vc + (size_t)sl * a.c_bs + (size_t)h * a.c_hs + (size_t)slot * 128 + d) = st;
   }
 }
 
 // Un-paired epilogues: tile `nt` of the unit (global n-tile index `ntile`), one wave.
-template <int NT, int EPI, int WAVES, int RH>
+struct NoRes {};
+template <int RH> struct ResPre { u32x2 v[RH]; };
+template <int NT, int EPI, int WAVES, int RH, typename RP = NoRes>
 __device__ __forceinline__ void epilogue_tile(const GemvArgs& a, const float (*red)[NT][RH][64][4], int nt, int ntile, int lane,
-                                              const float (*sh_ps)[RH][64]) {
+                                              const float (*sh_ps)[RH][64], const RP& rpre = RP()) {
   constexpr int SW = WAVES < 4 ? WAVES : 4;
   const int g = lane >> 4;
 #pragma unroll
@@ -323,7 +364,9 @@ __device__ __forceinline__ void epilogue_tile(const GemvArgs& a, const float (*r
     for (int r = 0; r < 4; ++r) y[r] = rbf(v[r] + bb[r]);
     if constexpr (EPI == EPI_RESIDUAL) {
       if (live) {
-        const u32x2 rv = *(const u32x2*)(a.R + (size_t)b * a.ldr + n);
+        u32x2 rv;
+        if constexpr (sizeof(RP) > 1) rv = rpre.v[hf];                                   // pipelined kernel: requested at entry
+        else rv = *(const u32x2*)(a.R + (size_t)b * a.ldr + n);
         y[0] += lo_bf(rv[0]); y[1] += hi_bf(rv[0]); y[2] += lo_bf(rv[1]); y[3] += hi_bf(rv[1]);
       }
       if (a.ssq_out) {   // sum of squares of the stored (bf16) values of this n-tile, per batch row
@@ -515,11 +558,35 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_pipe_kernel(GemvArgs a) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int KT = a.K >> 5;
   const int ntile0 = blockIdx.x * NT;
+#ifdef GEMV_ALL_VARIANTS
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+  if (a.dbg & 4) ts0 = __builtin_amdgcn_s_memrealtime();
+#endif
   ScaleRegs<RH> sc;
   scale_load<SW, RH>(a, sc, w, lane);                                // first loads of the wave (nothing waits for them until the end)
   uint16_t pv = 0;
   if constexpr (CW) {
     if (tid < 256) pv = a.patch[(size_t)blockIdx.x * 256 + tid];      // ahead of the weight loads: its wait leaves them in flight
+  }
+  // epilogue operands that exist before the launch: requested now by the waves that will run the epilogue
+  RopePre<RH> rope_pre;
+  ResPre<RH> res_pre;
+#pragma unroll
+  for (int hf = 0; hf < RH; ++hf) {
+    res_pre.v[hf] = u32x2{0u, 0u};
+    rope_pre.sl[hf] = -1; rope_pre.len[hf] = 1; rope_pre.cv[hf] = u32x2{0u, 0u}; rope_pre.sv[hf] = u32x2{0u, 0u};
+  }
+  if constexpr (EPI == EPI_ROPE_KV) {
+    if (a.row_meta && w < 2) rope_pre_load<RH>(a, rope_pre, blockIdx.x, lane, w == 0);
+  } else if constexpr (EPI == EPI_RESIDUAL) {
+    if (w < NT) {
+      const int n = (ntile0 + w) * 16 + 4 * (lane >> 4);
+#pragma unroll
+      for (int hf = 0; hf < RH; ++hf) {
+        const int b = (lane & 15) + 16 * hf;
+        if (b < a.M && n < a.Nvalid) res_pre.v[hf] = *(const u32x2*)(a.R + (size_t)b * a.ldr + n);
+      }
+    }
   }
   const int nk = (KT - w + WAVES - 1) / WAVES;                       // k-tiles kt = w + WAVES * i, i < nk (host: nk >= NB * U)
   const int nfull = nk / U;                                          // steps whose U k-tiles all exist
@@ -615,6 +682,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_pipe_kernel(GemvArgs a) {
     __syncthreads();
   }
   int s = 0;
+#ifdef GEMV_ALL_VARIANTS
+  if (a.dbg & 4) {   // first fragment landed (drains this wave's queue once: timing builds only)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ts1 = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
   for (; s + 2 * NB <= nfull; s += NB) {                              // steps s .. s + 2 NB - 1 are full: no branch around any load
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -640,20 +713,48 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_pipe_kernel(GemvArgs a) {
     for (int u = 0; u < U; ++u)
       if ((s + NB + b) * U + u < nk) mul1(wb[b][u], xb[b][u], (s + NB + b) * U + u);
 
+#ifdef GEMV_ALL_VARIANTS
+  if (a.dbg & 4) {
+    ts2 = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) a.dbg_ts[(size_t)gridDim.x * 4 + (size_t)blockIdx.x * 16 + w] = ts2 - ts0;   // per wave: entry -> k-loop done
+  }
+#endif
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
     for (int hf = 0; hf < RH; ++hf) *(f32x4*)&red[w][nt][hf][lane][0] = acc[nt][hf];
   scale_park<SW, RH>(a, sc, sh_ps, w, lane);
   __syncthreads();
-  if constexpr (EPI == EPI_SWIGLU || EPI == EPI_ROPE_KV) {
-    if (w == 0) epilogue_pair<NT, EPI, WAVES, RH>(a, red, blockIdx.x, lane, sh_ps);
-    if constexpr (NT == 3) {
-      if (w == (WAVES > 1 ? 1 : 0)) epilogue_vtile<NT, WAVES, RH>(a, red, blockIdx.x, lane, sh_ps);
+  if constexpr (EPI == EPI_ROPE_KV) {
+    static_assert(WAVES > 1, "the V tile's epilogue runs on wave 1");
+    if (a.row_meta) {
+      if (w == 0) epilogue_pair<NT, EPI, WAVES, RH, true>(a, red, blockIdx.x, lane, sh_ps, rope_pre);
+      if constexpr (NT == 3) {
+        if (w == 1) epilogue_vtile<NT, WAVES, RH, true>(a, red, blockIdx.x, lane, sh_ps, rope_pre);
+      }
+    } else {
+      if (w == 0) epilogue_pair<NT, EPI, WAVES, RH>(a, red, blockIdx.x, lane, sh_ps);
+      if constexpr (NT == 3) {
+        if (w == 1) epilogue_vtile<NT, WAVES, RH>(a, red, blockIdx.x, lane, sh_ps);
+      }
     }
+  } else if constexpr (EPI == EPI_SWIGLU) {
+    if (w == 0) epilogue_pair<NT, EPI, WAVES, RH>(a, red, blockIdx.x, lane, sh_ps);
+  } else if constexpr (EPI == EPI_RESIDUAL) {
+    if (w < NT) epilogue_tile<NT, EPI, WAVES, RH, ResPre<RH>>(a, red, w, ntile0 + w, lane, sh_ps, res_pre);
   } else {
     if (w < NT) epilogue_tile<NT, EPI, WAVES, RH>(a, red, w, ntile0 + w, lane, sh_ps);
   }
+#ifdef GEMV_ALL_VARIANTS
+  if ((a.dbg & 4) && w == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the epilogue's stores have left the wave
+    const unsigned long long ts3 = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) {
+      unsigned long long* o = a.dbg_ts + (size_t)blockIdx.x * 4;
+      o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = ts3;
+    }
+  }
+#endif
 }
 
 // Persistent form: a fixed grid (<= one workgroup per CU), each workgroup walks units u = blockIdx.x, + gridDim.x, ...

@@ -48,6 +48,10 @@ struct GemvArgs {
   RowMap map;                                   // decode row -> slot (state and cache rows)
   const bf16_t* cos_tab; const bf16_t* sin_tab; int maxpos;
   bf16_t* Kc; bf16_t* Vc; long c_bs, c_hs;
+  // EPI_ROPE_KV, optional (null: the epilogue chases map -> cur_len / kbeg -> cos / sin itself): what launch_embed_tokens left per
+  // decode ROW for this step -- row_meta[4 b] = {slot or -1, cached keys incl. this token, left pad, unfinished}, row_cos / row_sin
+  // [b][64] = the rotary table rows of the token's position. Read at kernel entry by the pipelined kernel.
+  const int* row_meta = nullptr; const bf16_t* row_cos = nullptr; const bf16_t* row_sin = nullptr;
   // decode-path activation buffers in the fragment-ordered layout (common.h xf_off): x_xf = X is, c_xf = C is written so
   // (EPI_SWIGLU only: its output feeds the down projection)
   int x_xf, c_xf;
@@ -69,6 +73,9 @@ struct GemvArgs {
   // tools/decode_bench only (gemv_pipe_kernel): timing experiments that keep the instruction stream and drop the memory requests --
   // bit 0: the activation descriptor has zero records, bit 1: the weight descriptor has (results are garbage)
   int dbg = 0;
+  // bit 2 (GEMV_ALL_VARIANTS builds): wave 0 of every workgroup writes s_memrealtime stamps (100 MHz) to dbg_ts[block][4]:
+  // kernel entry, first weight fragment landed, k-loop done, epilogue done
+  unsigned long long* dbg_ts = nullptr;
 };
 hipError_t launch_gemv_ex(const GemvArgs& a, int epi, int variant, hipStream_t s);
 void gemv_force_legacy(int on);   // tests / tools: 1 = run the r2 kernels (branchy k-loop) instead of the pipelined ones; same bits
@@ -122,6 +129,9 @@ struct DecodeAttnArgs {
   int B, H;
   float scale;
   int o_xf;                                  // write O in the fragment-ordered layout (common.h xf_off, 16-row images), k = h * 128 + d
+  // tools/decode_bench (GEMV_ALL_VARIANTS builds): s_memrealtime stamps per workgroup: [block][4] = entry, lengths known, key loop
+  // done (wave 0), end; then [block][16] per-wave (entry -> key loop done)
+  unsigned long long* dbg_ts = nullptr;
 };
 #define DECODE_NSPLIT 8   // capacity of the split-KV partial buffer; the launch picks 2..8 splits by batch
 hipError_t launch_decode_attention(const DecodeAttnArgs& a, hipStream_t s, int variant = 0);
@@ -156,8 +166,15 @@ hipError_t launch_gather_rows(const int* codes, const bf16_t* tok, const bf16_t*
 // out[r] = tok[id_r], id_r = ids_by_row[r] when given (teacher forcing), else ids_by_slot[map.slot[r]] (inactive row: token 0);
 // when ssq_part != null also part[r][0] = sum(out[r]^2), part[r][1..n_part) = 0; when out_xf != null the rows are also
 // written in the fragment-ordered layout (rows <= 32: two 16-row images)
+// meta (optional): per-row operands of this decode step's q/k/v epilogues (GemvArgs::row_meta / row_cos / row_sin), gathered here once
+struct RowMetaArgs {
+  const int* cur_len = nullptr; const int* kbeg = nullptr; const int* unfinished = nullptr;   // per slot
+  const bf16_t* cos_tab = nullptr; const bf16_t* sin_tab = nullptr; int maxpos = 0;
+  int* row_meta = nullptr; bf16_t* row_cos = nullptr; bf16_t* row_sin = nullptr;              // outputs: [rows][4], [rows][64], [rows][64]
+};
 hipError_t launch_embed_tokens(const int* ids_by_row, const int* ids_by_slot, const RowMap& map, const bf16_t* tok, bf16_t* out,
-                               int rows, int d, int vocab, float* ssq_part, int n_part, hipStream_t s, bf16_t* out_xf = nullptr);
+                               int rows, int d, int vocab, float* ssq_part, int n_part, hipStream_t s, bf16_t* out_xf = nullptr,
+                               const RowMetaArgs* meta = nullptr);
 hipError_t launch_view_reduce(const bf16_t* x, bf16_t* out, int B, int V, int n, int mode, hipStream_t s);
 hipError_t launch_pool2x2(const bf16_t* x, bf16_t* out, int n_img, int grid, int d, hipStream_t s);
 

@@ -165,10 +165,22 @@ __global__ __launch_bounds__(128) void gather_rows_kernel(const int* __restrict_
 __global__ __launch_bounds__(128) void embed_tokens_kernel(const int* __restrict__ ids_by_row, const int* __restrict__ ids_by_slot,
                                                            RowMap map, const bf16_t* __restrict__ tok,
                                                            bf16_t* __restrict__ out, int d, int vocab,
-                                                           float* __restrict__ ssq_part, int n_part, bf16_t* __restrict__ out_xf) {
+                                                           float* __restrict__ ssq_part, int n_part, bf16_t* __restrict__ out_xf,
+                                                           RowMetaArgs meta) {
   __shared__ float sh[2];
   const int row = blockIdx.x;
   const int sl = map.slot[row];
+  if (meta.row_meta && threadIdx.x < 64) {   // this step's per-row operands of the q/k/v epilogues (gemv.hip RopePre)
+    int len = 1, kb = 0, unf = 0, pos = 0;
+    if (sl >= 0) {
+      len = meta.cur_len[sl]; kb = meta.kbeg[sl]; unf = meta.unfinished ? meta.unfinished[sl] : 1;
+      const int pos_raw = len - 1 - kb;
+      pos = pos_raw < 0 ? 0 : (pos_raw >= meta.maxpos ? meta.maxpos - 1 : pos_raw);
+    }
+    if (threadIdx.x < 4) meta.row_meta[4 * row + threadIdx.x] = threadIdx.x == 0 ? sl : threadIdx.x == 1 ? len : threadIdx.x == 2 ? kb : unf;
+    meta.row_cos[row * 64 + threadIdx.x] = meta.cos_tab[(size_t)pos * 64 + threadIdx.x];
+    meta.row_sin[row * 64 + threadIdx.x] = meta.sin_tab[(size_t)pos * 64 + threadIdx.x];
+  }
   int id = ids_by_row ? ids_by_row[row] : (sl < 0 ? 0 : ids_by_slot[sl]);
   id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
   float ss = 0.f;
@@ -396,11 +408,14 @@ hipError_t launch_gather_rows(const int* codes, const bf16_t* tok, const bf16_t*
   return hipGetLastError();
 }
 hipError_t launch_embed_tokens(const int* ids_by_row, const int* ids_by_slot, const RowMap& map, const bf16_t* tok, bf16_t* out,
-                               int rows, int d, int vocab, float* ssq_part, int n_part, hipStream_t s, bf16_t* out_xf) {
+                               int rows, int d, int vocab, float* ssq_part, int n_part, hipStream_t s, bf16_t* out_xf,
+                               const RowMetaArgs* meta) {
   if (rows <= 0) return hipSuccess;
   if (rows > kMaxRows) return hipErrorInvalidValue;
+  if (meta && meta->row_meta && !(meta->cur_len && meta->kbeg && meta->cos_tab && meta->sin_tab && meta->row_cos && meta->row_sin && meta->maxpos > 0))
+    return hipErrorInvalidValue;
   hipLaunchKernelGGL(embed_tokens_kernel, dim3(rows), dim3(128), 0, s, ids_by_row, ids_by_slot, map, tok, out, d, vocab, ssq_part,
-                     n_part, out_xf);
+                     n_part, out_xf, meta ? *meta : RowMetaArgs());
   return hipGetLastError();
 }
 hipError_t launch_view_reduce(const bf16_t* x, bf16_t* out, int B, int V, int n, int mode, hipStream_t s) {

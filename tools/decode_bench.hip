@@ -103,6 +103,17 @@ int main(int argc, char** argv) {
     for (int b = 0; b < 16; ++b) h[b] = ctx;   // cur_len per row; kbeg (ints + 16) = 0
     CK(hipMemcpy(ints, h, sizeof(h), hipMemcpyHostToDevice));
   }
+  // per-row operands of the q/k/v epilogue as the engine's token gather leaves them (GemvArgs::row_meta / row_cos / row_sin)
+  int* row_meta;
+  CK(hipMalloc((void**)&row_meta, 32 * 4 * 4));
+  {
+    int h[128];
+    for (int b = 0; b < 32; ++b) { h[4 * b] = b < 16 ? b : -1; h[4 * b + 1] = ctx; h[4 * b + 2] = 0; h[4 * b + 3] = 1; }
+    CK(hipMemcpy(row_meta, h, sizeof(h), hipMemcpyHostToDevice));
+  }
+  const bf16_t* row_cos = cosb + (size_t)(ctx - 1) * 64;   // every row at position ctx - 1: 32 x 64 entries from there on are readable
+  const bf16_t* row_sin = sinb + (size_t)(ctx - 1) * 64;
+  const bool use_meta = !getenv("NO_META");
   float* part;
   CK(hipMalloc((void**)&part, (size_t)16 * H * DECODE_NSPLIT * 130 * 4));
   CK(hipDeviceSynchronize());
@@ -127,7 +138,7 @@ int main(int argc, char** argv) {
   printf("M=%d ctx=%d  (us per launch incl. ~1.5us boundary; GB/s = algorithmic weight bytes / time)\n", M, ctx);
   // ---- read ceiling
   for (size_t mb : {33, 90, 100, 180}) {
-    if (getenv("DBG_EXP")) break;
+    if (getenv("DBG_EXP") || getenv("TS_EXP")) break;
     const size_t bytes = mb << 20;
     for (int grid : {256, 512, 1024, 2048}) {
       float us = time_it([&](int i) {
@@ -146,7 +157,7 @@ int main(int argc, char** argv) {
       {"head f32       ", 32000, d, EPI_F32},
   };
   for (const Shape& sh : shapes) {
-    if (getenv("DBG_EXP")) break;
+    if (getenv("DBG_EXP") || getenv("TS_EXP")) break;
     const size_t wbytes = (size_t)sh.N * sh.K * 2;
     for (int variant = 0; variant <= 51; ++variant) {
       if (variant > 15 && variant < 40) continue;                    // 40..51: pipelined kernel (W, U, NB)
@@ -158,6 +169,7 @@ int main(int argc, char** argv) {
       a.H = H; a.kbeg = ints + 16; a.cur_len = ints; a.cos_tab = cosb; a.sin_tab = sinb;
       a.maxpos = 4096; a.Kc = Kc; a.Vc = Vc; a.c_bs = (long)H * Tmax * 128; a.c_hs = (long)Tmax * 128;
       a.ssq_out = ssq; a.x_xf = 1; a.c_xf = 1;
+      if (use_meta) { a.row_meta = row_meta; a.row_cos = row_cos; a.row_sin = row_sin; }
       hipError_t err = hipSuccess;
       float us = time_it([&](int i) {
         const size_t off = ((size_t)i * wbytes) % (pool_bytes - wbytes);
@@ -171,6 +183,117 @@ int main(int argc, char** argv) {
       else if (variant >= 40) printf("%s pipe W%-2d U%d NB%d : %7.2f us  %7.1f GB/s\n", sh.name, variant >= 46 ? 16 : 8, ((variant - 40) % 6) / 3 + 1, (variant - 40) % 3 + 2, us, wbytes / us * 1e-3);
       else printf("%s W%-2d U%d    : %7.2f us  %7.1f GB/s\n", sh.name, 1 << (vi / 3), variant == 15 ? 1 : 2 << (vi % 3), us, wbytes / us * 1e-3);
     }
+  }
+  // ---- where does a launch's time go? per-workgroup s_memrealtime stamps (10 ns) of two back-to-back launches
+  if (getenv("TS_EXP")) {
+    uint8_t* emin;
+    uint16_t* patch;
+    unsigned long long* ts;
+    CK(hipMalloc((void**)&emin, (size_t)8 << 20));
+    CK(hipMemset(emin, 56, (size_t)8 << 20));
+    CK(hipMalloc((void**)&patch, (size_t)4096 * 256 * 2));
+    CK(hipMemset(patch, 0, (size_t)4096 * 256 * 2));
+    const int NL = 6;
+    CK(hipMalloc((void**)&ts, (size_t)NL * 1024 * 20 * 8));
+    for (const Shape& sh : {shapes[0], shapes[1], shapes[3]}) {
+      const size_t wbytes = (size_t)sh.N * sh.K * 2;
+      GemvArgs a = {};
+      a.X = X; a.ldx = sh.K; a.bias = nullptr; a.R = R; a.ldr = sh.N; a.C = Y;
+      a.ldc = sh.epi == EPI_ROPE_KV ? d : sh.N;
+      a.M = M; a.N = sh.N; a.K = sh.K; a.Nvalid = sh.N;
+      a.H = H; a.kbeg = ints + 16; a.cur_len = ints; a.cos_tab = cosb; a.sin_tab = sinb;
+      a.maxpos = 4096; a.Kc = Kc; a.Vc = Vc; a.c_bs = (long)H * Tmax * 128; a.c_hs = (long)Tmax * 128;
+      a.ssq_out = ssq; a.x_xf = 1; a.c_xf = 1;
+      if (use_meta) { a.row_meta = row_meta; a.row_cos = row_cos; a.row_sin = row_sin; }
+      a.emin = emin; a.patch = patch; a.dbg = 4;
+      const int grid = sh.N / 16 / (sh.epi == EPI_ROPE_KV ? 3 : 1);
+      for (int cw = 0; cw < 2; ++cw) {
+        CK(hipMemset(ts, 0, (size_t)NL * 1024 * 20 * 8));
+        for (int rep = 0; rep < 3; ++rep)
+          for (int i = 0; i < NL; ++i) {
+            const size_t off = (((size_t)(i + rep * NL) * wbytes) % (pool_bytes - wbytes)) & ~(size_t)1023;
+            a.Wp = (const bf16_t*)((char*)pool + off);
+            a.Wc = cw ? (const uint8_t*)pool + off : nullptr;
+            a.dbg_ts = ts + (size_t)i * 1024 * 20;
+            CK(launch_gemv_ex(a, sh.epi, 0, s));
+          }
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> h((size_t)NL * 1024 * 20);
+        CK(hipMemcpy(h.data(), ts, h.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long prev_end = 0;
+        for (int i = 0; i < NL; ++i) {
+          unsigned long long t0min = ~0ull, t0max = 0, t1min = ~0ull, t1max = 0, t2min = ~0ull, t2max = 0, t3min = ~0ull, t3max = 0;
+          double sum1 = 0, sum2 = 0, sum3 = 0;
+          for (int g = 0; g < grid; ++g) {
+            const unsigned long long* q = &h[(size_t)i * 1024 * 20 + (size_t)g * 4];
+            t0min = q[0] < t0min ? q[0] : t0min; t0max = q[0] > t0max ? q[0] : t0max;
+            t1min = q[1] < t1min ? q[1] : t1min; t1max = q[1] > t1max ? q[1] : t1max;
+            t2min = q[2] < t2min ? q[2] : t2min; t2max = q[2] > t2max ? q[2] : t2max;
+            t3min = q[3] < t3min ? q[3] : t3min; t3max = q[3] > t3max ? q[3] : t3max;
+            sum1 += (double)(q[1] - q[0]); sum2 += (double)(q[2] - q[1]); sum3 += (double)(q[3] - q[2]);
+          }
+          printf("%s %s launch %d: gap after previous end %6.2f us | entry spread %5.2f | first fragment: mean %5.2f (last wg at %5.2f) | k-loop: mean %5.2f (last done at %5.2f) | epilogue: mean %5.2f | last wg end at %6.2f us\n",
+                 sh.name, cw ? "compressed" : "plain     ", i, prev_end ? (double)(long long)(t0min - prev_end) * 0.01 : 0.0, (t0max - t0min) * 0.01,
+                 sum1 / grid * 0.01, (t1max - t0min) * 0.01, sum2 / grid * 0.01, (t2max - t0min) * 0.01, sum3 / grid * 0.01, (t3max - t0min) * 0.01);
+          prev_end = t3max;
+          if (i == NL - 1) {   // per wave: mean / max over the workgroups of (entry -> k-loop done)
+            printf("    per-wave k-loop done (mean us over workgroups):");
+            for (int wv = 0; wv < 16; ++wv) {
+              double sm = 0; int cnt = 0;
+              for (int g = 0; g < grid; ++g) { const unsigned long long v = h[(size_t)i * 1024 * 20 + (size_t)grid * 4 + (size_t)g * 16 + wv]; if (v) { sm += (double)v; ++cnt; } }
+              if (cnt) printf(" %5.2f", sm / cnt * 0.01);
+            }
+            printf("\n");
+          }
+        }
+      }
+    }
+    {   // decode attention, the same stamps
+      DecodeAttnArgs a = {};
+      a.o_xf = 1;
+      a.Q = X; a.q_bs = d; a.c_bs = (long)H * Tmax * 128; a.c_hs = (long)Tmax * 128; a.O = Y; a.o_bs = d;
+      a.part = part; a.kbeg = ints + 16; a.cur_len = ints; a.B = M; a.H = H; a.scale = 0.0883883f;
+      const int grid = M * H;
+      for (int variant : {0, 14, 17}) {
+        CK(hipMemset(ts, 0, (size_t)NL * 1024 * 20 * 8));
+        for (int rep = 0; rep < 3; ++rep)
+          for (int i = 0; i < NL; ++i) {
+            a.Kc = Kc + (size_t)((i + rep) % 8) * kv_elems;
+            a.Vc = Vc + (size_t)((i + rep) % 8) * kv_elems;
+            a.dbg_ts = ts + (size_t)i * 1024 * 20;
+            CK(launch_decode_attention(a, s, variant));
+          }
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> h((size_t)NL * 1024 * 20);
+        CK(hipMemcpy(h.data(), ts, h.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long prev_end = 0;
+        for (int i = 0; i < NL; ++i) {
+          unsigned long long t0min = ~0ull, t0max = 0, t2max = 0, t3max = 0;
+          double sum1 = 0, sum2 = 0, sum3 = 0;
+          for (int g = 0; g < grid; ++g) {
+            const unsigned long long* q = &h[(size_t)i * 1024 * 20 + (size_t)g * 4];
+            t0min = q[0] < t0min ? q[0] : t0min; t0max = q[0] > t0max ? q[0] : t0max;
+            t2max = q[2] > t2max ? q[2] : t2max; t3max = q[3] > t3max ? q[3] : t3max;
+            sum1 += (double)(q[1] - q[0]); sum2 += (double)(q[2] - q[1]); sum3 += (double)(q[3] - q[2]);
+          }
+          if (i >= NL - 2)
+            printf("attention v%d launch %d: gap %6.2f us | entry spread %5.2f | lengths known: mean %5.2f | key loop (wave 0): mean %5.2f (last done at %5.2f) | merge + store: mean %5.2f | last wg end at %6.2f us\n",
+                   variant, i, prev_end ? (double)(long long)(t0min - prev_end) * 0.01 : 0.0, (t0max - t0min) * 0.01, sum1 / grid * 0.01,
+                   sum2 / grid * 0.01, (t2max - t0min) * 0.01, sum3 / grid * 0.01, (t3max - t0min) * 0.01);
+          prev_end = t3max;
+          if (i == NL - 1) {
+            printf("    per-wave key loop done (mean us over workgroups):");
+            for (int wv = 0; wv < 16; ++wv) {
+              double sm = 0; int cnt = 0;
+              for (int g = 0; g < grid; ++g) { const unsigned long long v = h[(size_t)i * 1024 * 20 + (size_t)grid * 4 + (size_t)g * 16 + wv]; if (v) { sm += (double)v; ++cnt; } }
+              if (cnt) printf(" %5.2f", sm / cnt * 0.01);
+            }
+            printf("\n");
+          }
+        }
+      }
+    }
+    return 0;
   }
   // ---- what bounds the one-unit kernels? the same launch with the activation requests and / or the weight requests dropped by the
   // descriptors' range check (instruction stream, waits and epilogue unchanged)
@@ -190,6 +313,7 @@ int main(int argc, char** argv) {
       a.H = H; a.kbeg = ints + 16; a.cur_len = ints; a.cos_tab = cosb; a.sin_tab = sinb;
       a.maxpos = 4096; a.Kc = Kc; a.Vc = Vc; a.c_bs = (long)H * Tmax * 128; a.c_hs = (long)Tmax * 128;
       a.ssq_out = ssq; a.x_xf = 1; a.c_xf = 1;
+      if (use_meta) { a.row_meta = row_meta; a.row_cos = row_cos; a.row_sin = row_sin; }
       a.emin = emin; a.patch = patch;
       for (int cw = 0; cw < 2; ++cw)
         for (int dbg = 0; dbg < 4; ++dbg)
@@ -226,6 +350,7 @@ int main(int argc, char** argv) {
       a.H = H; a.kbeg = ints + 16; a.cur_len = ints; a.cos_tab = cosb; a.sin_tab = sinb;
       a.maxpos = 4096; a.Kc = Kc; a.Vc = Vc; a.c_bs = (long)H * Tmax * 128; a.c_hs = (long)Tmax * 128;
       a.ssq_out = ssq; a.x_xf = 1; a.c_xf = 1;
+      if (use_meta) { a.row_meta = row_meta; a.row_cos = row_cos; a.row_sin = row_sin; }
       a.emin = emin; a.patch = patch;
       for (int cw = 0; cw < 2; ++cw) {
         hipError_t err = hipSuccess;
