@@ -115,8 +115,8 @@ int orc_read_state(orc_engine* e, int32_t* tokens_host, int32_t* steps_host, int
                    int32_t* last_argmax_host, void* stream);
 
 /* per-row length stops of the running batch (after orc_prefill; default = max_new_tokens for every row): row b is finished
- * once it has emitted limits_host[b] tokens (>= 2: the first token is sampled by the prefill itself) or EOS, whichever comes
- * first -- what max_new_tokens is to the whole batch in the reference's generate() call
+ * once it has emitted limits_host[b] tokens (1..max_new_tokens; the first token was sampled by the prefill itself, so a row with
+ * limit 1 is marked finished by this call) or EOS, whichever comes first -- what max_new_tokens is to the whole batch in the reference's generate() call
  * (scene_graph_prediction_model_oracle.py:135-143), per row; used for synthetic answer-length distributions. */
 int orc_set_row_limits(orc_engine* e, const int32_t* limits_host, int n, void* stream);
 
@@ -169,6 +169,11 @@ int64_t orc_kv_bytes_per_key(orc_engine* e);
  * which = 0: one whole decode step; which = 1: one gate/up launch (the kernel orc_profile_read samples). No counterpart in the
  * reference (measurement only). */
 int64_t orc_decode_stream_bytes(orc_engine* e, int which);
+/* Bookkeeping of those 12-bit copies, out6 = {decode weight matrices, matrices that took the 12-bit stream, weight elements,
+ * escaped elements (patch-table entries), 1-KiB blocks, blocks with at least one escape}. A matrix with a GEMV unit of more than
+ * 254 non-zero out-of-range elements keeps bf16: orc_engine_finalize says so on stderr, once per matrix and once in total.
+ * No counterpart in the reference (measurement only). */
+int orc_decode_weight_stats(orc_engine* e, int64_t* out6);
 
 #ifdef __cplusplus
 }

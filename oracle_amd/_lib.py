@@ -60,6 +60,7 @@ SYMBOLS = {
     'orc_decode_weight_bytes': (_L, [_P]),
     'orc_kv_bytes_per_key': (_L, [_P]),
     'orc_decode_stream_bytes': (_L, [_P, _I]),
+    'orc_decode_weight_stats': (_I, [_P, C.POINTER(_L)]),
 }
 
 

@@ -223,6 +223,12 @@ class Engine:
     def kv_bytes_per_key(self):
         return int(self.lib.orc_kv_bytes_per_key(self._h))
 
+    def decode_weight_stats(self):
+        """Bookkeeping of the lossless 12-bit decode copies: dict(matrices, compressed, elements, escapes, blocks, flagged_blocks)."""
+        out = (C.c_int64 * 6)()
+        _lib.check(self.lib.orc_decode_weight_stats(self._h, out), 'orc_decode_weight_stats')
+        return dict(zip(('matrices', 'compressed', 'elements', 'escapes', 'blocks', 'flagged_blocks'), [int(v) for v in out]))
+
     def decode_stream_bytes(self, which=0):
         """Physical weight bytes streamed per decode step (which=0) or per gate/up launch (which=1): 12-bit copies where active."""
         return int(self.lib.orc_decode_stream_bytes(self._h, which))

@@ -288,7 +288,13 @@ class LlavaLlamaForCausalLM(LlavaMetaForCausalLM):
             for i, f in enumerate(frames):
                 emb[i, t - lens[i]:] = f[2]
                 pos[i, t - lens[i]:] = torch.arange(lens[i], dtype=torch.int32)
-            eng.prefill_slots(slots, emb, pos, [t - n for n in lens], [min(f[3], eng.max_seq - t) for f in frames])
+            lims = [min(f[3], eng.max_seq - t) for f in frames]
+            if any(l_ < f[3] for l_, f in zip(lims, frames)):
+                # frames of different incoming batches share this prefill: the padded length t can exceed the frame's own
+                # batch length, and the KV capacity then cuts its answer shorter than generate() would (which warns too)
+                warnings.warn(f'stream prefill padded to {t} tokens: length stops lowered to the KV capacity {eng.max_seq} '
+                              f'({[f[3] for f in frames]} -> {lims})')
+            eng.prefill_slots(slots, emb, pos, [t - n for n in lens], lims)
             waiting.extend((s_, f[0], f[1]) for s_, f in zip(slots, frames))
 
         def schedule():

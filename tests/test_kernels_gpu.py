@@ -282,6 +282,46 @@ def test_compressed_weight_stream_is_bit_exact(epi, N, K, M):
         assert torch.equal(plain.view(torch.int32 if epi == 'f32' else torch.int16), packed.view(torch.int32 if epi == 'f32' else torch.int16))
 
 
+def _shaped_weights(kind, N, K, seed):
+    """Weight distributions a trained / LoRA-merged LLaMA shows and a random init does not."""
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn(N, K, generator=g) * 0.02
+    if kind == 'student_t3':                                   # heavy tails: block maxima 10-20 sigma
+        chi = (torch.randn(3, N, K, generator=g) ** 2).sum(0) / 3
+        w = w / chi.sqrt()
+    elif kind == 'outlier_channels':                           # a few input channels 30x, a few output rows 8x (massive activations' partners)
+        cols = torch.randperm(K, generator=g)[:8]                # (a whole row 20x lifts its 16-row tile 4-5 binades: > 254 escapes in a
+        rows = torch.randperm(N, generator=g)[:6]                #  K = 11008 unit, the matrix then keeps bf16 -- DESIGN 3 table)
+        w[:, cols] *= 30.0
+        w[rows] *= 8.0
+    elif kind == 'lognormal_rows':                             # per-row scales e^N(0, 0.5): the 16 rows of a block spread over ~4 binades
+        w = w * torch.exp(torch.randn(N, 1, generator=g) * 0.5)
+    elif kind == 'lora_merged':                                # W + (alpha / r) B A, r = 16, alpha / r = 2 (the released checkpoints' merge)
+        a_ = torch.randn(16, K, generator=g) * 0.02
+        b_ = torch.randn(N, 16, generator=g) * 0.05
+        w = w + 2.0 * (b_ @ a_)
+    else:
+        raise ValueError(kind)
+    return w.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize('kind', ['student_t3', 'outlier_channels', 'lognormal_rows', 'lora_merged'])
+@pytest.mark.parametrize('epi,N,K', [('swiglu', 22016, 4096), ('residual', 4096, 11008), ('none', 12288, 4096), ('f32', 32000, 4096)])
+def test_compressed_weight_stream_on_non_gaussian_weights(kind, epi, N, K):
+    """The 12-bit stream at the 7B shapes on heavy-tailed, outlier-channel, per-row-scaled and LoRA-merged weights: every matrix
+    takes it (no unit above 254 patch entries) and every output bit equals the bf16 stream's. tools/decode_bench DIST_EXP times
+    the same distributions (table in DESIGN 3)."""
+    from oracle_amd import engine as E
+    d = _dev()
+    w = _shaped_weights(kind, N, K, 71).to(d)
+    x = _rand((8, K), 72).to(d)
+    res = _rand((8, N), 73).to(d) if epi == 'residual' else None
+    plain = E.test_gemm(x, w, None, res, epi, use_gemv=True)
+    packed = E.test_gemm(x, w, None, res, epi, use_gemv='cw')
+    v = torch.int32 if epi == 'f32' else torch.int16
+    assert torch.equal(plain.view(v), packed.view(v))
+
+
 @pytest.mark.parametrize('M', [1, 8, 16, 17, 32])
 @pytest.mark.parametrize('epi,N,K', [('residual', 4096, 11008), ('residual', 4096, 4096), ('none', 12288, 4096), ('residual', 512, 1408),
                                      ('none', 4096, 2048), ('residual', 1024, 768 * 4)])

@@ -93,6 +93,42 @@ def test_stream_length_stops_and_capacity(chain):
     assert steps[5] == 4 and unf[5] == 0 and len(steps) == 8
 
 
+def test_stream_mixes_batches_of_very_different_prompt_lengths(chain):
+    """Incoming batches whose prompts differ by ~100 tokens share stream prefills (a short frame is then left-padded far beyond its
+    own batch's length: different pad offset, different tile alignment, different co-batched rows than in generate()): the
+    tokens must still be generate()'s for every batch. Tokens, not logits bits, are what this guarantees."""
+    import random
+    from oracle_amd.dims import TINY
+    from oracle_amd.synth import CHAIN_BASE, CHAIN_LEN, synth_images
+    st, eng, model = chain
+    rng = random.Random(77)
+    e = CHAIN_BASE + CHAIN_LEN
+    items = []
+    for k, (b, extra) in enumerate([(3, 0), (2, 110), (4, 5), (1, 64), (3, 0)]):
+        rows = [[1] + [rng.randrange(3, 1000) for _ in range(extra + rng.randint(0, 4))] + [-200] + [rng.randrange(3, 1000) for _ in range(rng.randint(0, 3))]
+                + [e - rng.randint(2, 24)] for _ in range(b)]
+        L = max(len(r) for r in rows)
+        ids = torch.tensor([[0] * (L - len(r)) + r for r in rows])
+        items.append({'input_ids': ids.cuda(), 'images': synth_images(b, 3, TINY, seed=900 + k).cuda()})
+    outs = [o.cpu() for o in model.generate_stream(iter(items), max_new_tokens=32, n_rows=4, chunk=3)]
+    for k, (item, out) in enumerate(zip(items, outs)):
+        ref = model.generate(item['input_ids'], images=item['images'], max_new_tokens=32).cpu()
+        assert torch.equal(out, ref), k
+
+
+def test_generate_row_limit_of_one_emits_one_token(chain):
+    """orc_set_row_limits with a limit of 1: the prefill's own token is the row's only one (r2 emitted a second token: ADVICE)."""
+    st, eng, model = chain
+    item = _batches([4], seed=5)[0]
+    L = item['input_ids'].shape[1]
+    free = model.generate(item['input_ids'], images=item['images'], max_new_tokens=20).cpu()
+    out = model.generate(item['input_ids'], images=item['images'], max_new_tokens=20, limits=[1, 20, 1, 3]).cpu()
+    for b, lim in enumerate([1, 20, 1, 3]):
+        n = min(lim, int((free[b, L:] != 0).sum()))
+        assert torch.equal(out[b, L:L + n], free[b, L:L + n]), b
+        assert bool((out[b, L + n:] == 0).all()), (b, out[b, L:])
+
+
 def test_stream_16_rows_over_32_slots_equals_generate():
     """Decode width 16 over 32 KV-cache slots (two of the reference's batches of 8 decode side by side, the next two wait
     prefilled): still exactly generate()'s tokens for every incoming batch."""
