@@ -146,6 +146,12 @@ int orc_read_slots(orc_engine* e, int32_t* tokens_host, int32_t* row_steps_host,
 int orc_test_gemm(const void* x, int M, int K, const void* w_rowmajor, int N, const void* bias, const void* residual,
                   int epilogue, int use_gemv, void* out, void* stream);
 int orc_test_rmsnorm(const void* x, const void* w, int rows, int d, float eps, void* out, void* stream);
+/* RMSNorm -> Linear of the decode path, both ways (LlamaDecoderLayer's input_layernorm -> q/k/v_proj etc. under
+ * LLaVA/llava/model/language_model/llava_llama.py:87-98): out_exact = Linear(rmsnorm(x)) with the reference's rounding points,
+ * out_folded = the engine's default decode arithmetic (norm weight folded into the weight copy, row scale in the GEMV epilogue;
+ * ORC_DECODE_NORM=exact switches the engine to the first form). x (M <= 32, K) bf16, w_norm (K), w (N, K); outputs (M, N) bf16. */
+int orc_test_folded_norm(const void* x, int M, int K, const void* w_norm, const void* w, int N, float eps, void* out_exact,
+                         void* out_folded, void* stream);
 int orc_test_layernorm(const void* x, const void* w, const void* b, int rows, int d, float eps, void* out, void* stream);
 int orc_test_attention(const void* q, const void* k, const void* v, int B, int H, int Sq, int Sk, int head_dim,
                        const int32_t* kbeg, const int32_t* kend, int causal, int q_off, float scale, void* out,

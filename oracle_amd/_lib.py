@@ -52,6 +52,7 @@ SYMBOLS = {
     'orc_read_slots': (_I, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P]),
     'orc_test_gemm': (_I, [_P, _I, _I, _P, _I, _P, _P, _I, _I, _P, _P]),
     'orc_test_rmsnorm': (_I, [_P, _P, _I, _I, _F, _P, _P]),
+    'orc_test_folded_norm': (_I, [_P, _I, _I, _P, _P, _I, _F, _P, _P, _P]),
     'orc_test_layernorm': (_I, [_P, _P, _P, _I, _I, _F, _P, _P]),
     'orc_test_attention': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _F, _P, _P]),
     'orc_test_decode_attention': (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _P, _P]),

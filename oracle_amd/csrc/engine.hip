@@ -117,6 +117,10 @@ struct orc_engine {
   int *d_step, *d_nunf, *d_unf, *d_next, *d_argmax, *d_kbeg, *d_kend, *d_rowoff, *d_rowvalid, *d_curlen, *d_rowstep, *d_limit, *d_tokens;
   int* d_pfkbeg = nullptr;   // [16] left pad of the rows of the prefill being launched (attention reads it per launch row)
   bool compress_decode = true;   // ORC_DECODE_WEIGHTS=plain turns the 12-bit decode copies off (A/B runs)
+  // ORC_DECODE_NORM=exact: the decode path runs every RMSNorm as its own launch with the reference's rounding points (fp32
+  // statistics, bf16(x * r) * w: the prefill's kernel) in front of un-folded decode weight copies, instead of folding the norm
+  // weight into the projection and the row scale into its epilogue (A/B switch for the folded norm's changed rounding points)
+  bool fold_norm = true;
   // bookkeeping of the 12-bit copies (orc_decode_weight_stats): decode matrices seen / compressed, their elements and escapes
   int64_t cw_mats = 0, cw_done = 0, cw_elems = 0, cw_escapes = 0, cw_flagged_blocks = 0, cw_blocks = 0;
   bool stream_mode = false;  // continuous batching (orc_stream_begin): decode rows are re-pointed at slots prefilled ahead
@@ -446,11 +450,17 @@ extern "C" int orc_engine_finalize(orc_engine* e) {
   ORCCHK(take(e, "model.embed_tokens.weight", &e->embed, (size_t)c.vocab * c.d_model));
   ORCCHK(take(e, "model.norm.weight", &e->final_norm, c.d_model));
   ORCCHK(pack_rows(e, {"lm_head.weight"}, c.d_model, nullptr, 256, &e->lm_head));
-  ORCCHK(pack_rows(e, {"lm_head.weight"}, c.d_model, nullptr, 256, &e->lm_head_dec, e->final_norm));
+  {
+    const char* nm = getenv("ORC_DECODE_NORM");
+    e->fold_norm = !(nm && strcmp(nm, "exact") == 0);
+  }
+  ORCCHK(pack_rows(e, {"lm_head.weight"}, c.d_model, nullptr, 256, &e->lm_head_dec, e->fold_norm ? e->final_norm : nullptr));
   free_raw(e, {"lm_head.weight"});
   {
     const char* m = getenv("ORC_DECODE_WEIGHTS");
     e->compress_decode = !(m && strcmp(m, "plain") == 0);
+    const char* nm = getenv("ORC_DECODE_NORM");
+    e->fold_norm = !(nm && strcmp(nm, "exact") == 0);
   }
   ORCCHK(compress_for_decode(e, &e->lm_head_dec, EPI_F32, true, "lm_head"));
   e->llama.resize(c.n_layers);
@@ -476,11 +486,11 @@ extern "C" int orc_engine_finalize(orc_engine* e) {
     ORCCHK(take(e, q + "post_attention_layernorm.weight", &L.ln_post, c.d_model));
     std::vector<std::string> w3 = {q + "self_attn.q_proj.weight", q + "self_attn.k_proj.weight", q + "self_attn.v_proj.weight"};
     ORCCHK(pack_rows(e, w3, c.d_model, nullptr, 256, &L.qkv));
-    ORCCHK(pack_rows(e, w3, c.d_model, &qkv_dec_map, 256, &L.qkv_dec, L.ln_in));
+    ORCCHK(pack_rows(e, w3, c.d_model, &qkv_dec_map, 256, &L.qkv_dec, e->fold_norm ? L.ln_in : nullptr));
     ORCCHK(pack_rows(e, {q + "self_attn.o_proj.weight"}, c.d_model, nullptr, 256, &L.o));
     std::vector<std::string> w2 = {q + "mlp.gate_proj.weight", q + "mlp.up_proj.weight"};
     ORCCHK(pack_rows(e, w2, c.d_model, &gu_map, 256, &L.gu));
-    ORCCHK(pack_rows(e, w2, c.d_model, &gu_map, 256, &L.gu_dec, L.ln_post));
+    ORCCHK(pack_rows(e, w2, c.d_model, &gu_map, 256, &L.gu_dec, e->fold_norm ? L.ln_post : nullptr));
     ORCCHK(pack_rows(e, {q + "mlp.down_proj.weight"}, c.d_ff, nullptr, 256, &L.down));
     ORCCHK(compress_for_decode(e, &L.qkv_dec, EPI_ROPE_KV, true, (q + "self_attn.{q,k,v}_proj").c_str()));
     ORCCHK(compress_for_decode(e, &L.gu_dec, EPI_SWIGLU, true, (q + "mlp.{gate,up}_proj").c_str()));
@@ -810,7 +820,12 @@ static int llama_decode_layers(orc_engine* e, int B, hipStream_t s, bool skip_fi
     const LlamaLayer& L = e->llama[i];
     bf16_t* kc = e->kcache + (size_t)i * e->kv_layer_elems;
     bf16_t* vc = e->vcache + (size_t)i * e->kv_layer_elems;
-    ORCCHK(gemv_ex(e, hxf, d, L.qkv_dec, nullptr, q, d, B, EPI_ROPE_KV, s, kc, vc, nullptr, 1, 0, nullptr, nullptr, e->d_ssq));
+    if (e->fold_norm) {
+      ORCCHK(gemv_ex(e, hxf, d, L.qkv_dec, nullptr, q, d, B, EPI_ROPE_KV, s, kc, vc, nullptr, 1, 0, nullptr, nullptr, e->d_ssq));
+    } else {   // ORC_DECODE_NORM=exact
+      HIPCHK(launch_rmsnorm(h, d, L.ln_in, e->d_xn, d, B, d, c.rms_eps, s));
+      ORCCHK(gemv_ex(e, e->d_xn, d, L.qkv_dec, nullptr, q, d, B, EPI_ROPE_KV, s, kc, vc, nullptr, 0, 0));
+    }
     DecodeAttnArgs a;
     a.o_xf = 1;
     a.Q = q; a.q_bs = d; a.Kc = kc; a.Vc = vc; a.c_bs = e->c_bs; a.c_hs = e->c_hs; a.O = att; a.o_bs = d;
@@ -823,8 +838,9 @@ static int llama_decode_layers(orc_engine* e, int B, hipStream_t s, bool skip_fi
     const bool sample = e->prof_on && (i % 8 == 0) && e->ev_used < (int)e->ev_a.size();
     // sampled launches carry their own start / stop events (the dispatch's timestamps, not a pair of event commands
     // around it, which would add the launch boundary)
-    ORCCHK(gemv_ex(e, hxf, d, L.gu_dec, nullptr, mlp, c.d_ff, B, EPI_SWIGLU, s, nullptr, nullptr, nullptr, 1, 1,
-                   sample ? e->ev_a[e->ev_used] : nullptr, sample ? e->ev_b[e->ev_used] : nullptr, e->d_ssq));
+    if (!e->fold_norm) HIPCHK(launch_rmsnorm(h, d, L.ln_post, e->d_xn, d, B, d, c.rms_eps, s));
+    ORCCHK(gemv_ex(e, e->fold_norm ? hxf : e->d_xn, d, L.gu_dec, nullptr, mlp, c.d_ff, B, EPI_SWIGLU, s, nullptr, nullptr, nullptr, e->fold_norm ? 1 : 0, 1,
+                   sample ? e->ev_a[e->ev_used] : nullptr, sample ? e->ev_b[e->ev_used] : nullptr, e->fold_norm ? e->d_ssq : nullptr));
     if (sample) ++e->ev_used;
     ORCCHK(gemv_ex(e, mlp, c.d_ff, L.down, h, h, d, B, EPI_RESIDUAL, s, nullptr, nullptr, e->d_ssq, 1, 0, nullptr, nullptr, nullptr, hxf));
   }
@@ -836,7 +852,10 @@ static int llama_decode_layers(orc_engine* e, int B, hipStream_t s, bool skip_fi
 static int head_and_sample(orc_engine* e, const bf16_t* hrows, int ldh, int B, float* logits_out, bool from_decode, hipStream_t s,
                            const RowMap& sm, bool freeze = true) {
   const orc_config& c = e->c;
-  if (from_decode) {   // final RMSNorm folded into the lm_head projection (raw rows in d_hxf, partials in d_ssq)
+  if (from_decode && !e->fold_norm) {   // ORC_DECODE_NORM=exact
+    HIPCHK(launch_rmsnorm(e->d_h, c.d_model, e->final_norm, e->d_xn, c.d_model, B, c.d_model, c.rms_eps, s));
+    ORCCHK(gemv_ex(e, e->d_xn, c.d_model, e->lm_head_dec, nullptr, e->w_logits, c.vocab, B, EPI_F32, s));
+  } else if (from_decode) {   // final RMSNorm folded into the lm_head projection (raw rows in d_hxf, partials in d_ssq)
     ORCCHK(gemv_ex(e, e->d_hxf, c.d_model, e->lm_head_dec, nullptr, e->w_logits, c.vocab, B, EPI_F32, s, nullptr, nullptr, nullptr, 1, 0,
                    nullptr, nullptr, e->d_ssq));
   } else {
@@ -1164,6 +1183,48 @@ extern "C" int orc_test_gemm(const void* x, int M, int K, const void* w, int N, 
   HIPCHK(hipStreamSynchronize(s));
   HIPCHK(hipFree(wp));
   if (rm) HIPCHK(hipFree(rm));
+  return 0;
+}
+
+// RMSNorm -> Linear at decode shapes, both ways (tests/test_kernels_gpu.py::test_folded_rmsnorm_against_exact):
+//   out_exact  = GEMV(W, rmsnorm(x; w_norm))                       the reference's rounding points (the prefill's norm kernel)
+//   out_folded = r_b * GEMV(bf16(W * diag(w_norm)), x raw)         the decode path: norm weight folded into the weight copy, row
+//                                                                  scale from per-16-column partial sums of squares in the epilogue
+// x (M, K) bf16, w_norm (K) bf16, w (N, K) bf16 row-major, outputs (M, N) bf16. M <= 32, K % 256 == 0, N % 256 == 0.
+extern "C" int orc_test_folded_norm(const void* x, int M, int K, const void* w_norm, const void* w, int N, float eps,
+                                    void* out_exact, void* out_folded, void* stream) {
+  hipStream_t s = S(stream);
+  if (M < 1 || M > kMaxRows || (K % 256) || (N % 256)) return fail("orc_test_folded_norm", "M in 1..32, K and N multiples of 256");
+  bf16_t *wp, *wf, *xn, *xf;
+  float* ssq;
+  HIPCHK(hipMalloc((void**)&wp, (size_t)N * K * 2));
+  HIPCHK(hipMalloc((void**)&wf, (size_t)N * K * 2));
+  HIPCHK(hipMalloc((void**)&xn, (size_t)kMaxRows * K * 2));
+  HIPCHK(hipMalloc((void**)&xf, (size_t)kMaxRows * K * 2));
+  HIPCHK(hipMalloc((void**)&ssq, (size_t)kMaxRows * (K / 16) * 4));
+  HIPCHK(launch_pack_weight((const bf16_t*)w, N, K, nullptr, wp, N, K, s));
+  HIPCHK(launch_pack_weight((const bf16_t*)w, N, K, nullptr, wf, N, K, s, (const bf16_t*)w_norm));
+  // the raw rows fragment-ordered + their per-16-column sums of squares, as the residual epilogues leave them: an identity
+  // "token gather" over x (vocab = M, ids = row index)
+  std::vector<int> ids(M);
+  for (int i = 0; i < M; ++i) ids[i] = i;
+  int* dids;
+  HIPCHK(hipMalloc((void**)&dids, M * 4));
+  HIPCHK(hipMemcpyAsync(dids, ids.data(), M * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(launch_embed_tokens(dids, nullptr, identity_map(), (const bf16_t*)x, xn, M, K, M, ssq, K / 16, s, xf));
+  // exact
+  HIPCHK(launch_rmsnorm((const bf16_t*)x, K, (const bf16_t*)w_norm, xn, K, M, K, eps, s));
+  GemvArgs a = {};
+  a.map = identity_map();
+  a.X = xn; a.ldx = K; a.Wp = wp; a.C = out_exact; a.ldc = N; a.M = M; a.N = N; a.K = K; a.Nvalid = N;
+  hipError_t err = launch_gemv_ex(a, EPI_NONE, 0, s);
+  // folded
+  GemvArgs f = a;
+  f.X = xf; f.x_xf = 1; f.Wp = wf; f.C = out_folded; f.ssq_in = ssq; f.n_part = K / 16; f.norm_d = K; f.norm_eps = eps;
+  hipError_t err2 = launch_gemv_ex(f, EPI_NONE, 0, s);
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipFree(wp)); HIPCHK(hipFree(wf)); HIPCHK(hipFree(xn)); HIPCHK(hipFree(xf)); HIPCHK(hipFree(ssq)); HIPCHK(hipFree(dids));
+  if (err != hipSuccess || err2 != hipSuccess) return fail("orc_test_folded_norm", hipGetErrorString(err != hipSuccess ? err : err2));
   return 0;
 }
 

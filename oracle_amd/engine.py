@@ -251,6 +251,16 @@ def test_gemm(x, w, bias=None, residual=None, epilogue='none', use_gemv=False, k
     return out
 
 
+def test_folded_norm(x, w_norm, w, eps):
+    """-> (Linear(rmsnorm(x)) with the reference's rounding points, the decode path's folded form), both (M, N) bf16."""
+    m, k = x.shape
+    n = w.shape[0]
+    a = torch.empty(m, n, dtype=torch.bfloat16, device=x.device)
+    b = torch.empty_like(a)
+    _lib.check(_lib.lib().orc_test_folded_norm(_ptr(x), m, k, _ptr(w_norm), _ptr(w), n, eps, _ptr(a), _ptr(b), _stream()), 'orc_test_folded_norm')
+    return a, b
+
+
 def test_rmsnorm(x, w, eps):
     out = torch.empty_like(x)
     _lib.check(_lib.lib().orc_test_rmsnorm(_ptr(x), _ptr(w), x.shape[0], x.shape[1], eps, _ptr(out), _stream()), 'rmsnorm')

@@ -24,16 +24,26 @@ def _trim(ids):
     return ids[:, first:]
 
 
-@pytest.fixture(scope='module')
-def select_model():
+@pytest.fixture(scope='module', params=['folded', 'exact'])
+def select_model(request):
+    """Both decode-norm forms: the default (RMSNorm folded into the consuming projection) and ORC_DECODE_NORM=exact (the reference's
+    rounding points, a separate norm launch) -- read by the engine when its weights are finalized."""
     from oracle_amd.dims import TINY
     from oracle_amd.engine import Engine
     from oracle_amd.llava.model.language_model.llava_llama import LlavaConfig, LlavaLlamaForCausalLM
     from oracle_amd.synth import install_select_chains, synth_state
     g = np.load(os.path.join(GOLDEN, 'select_tiny_bfloat16.npz'))
     st = install_select_chains(synth_state(TINY, seed=0), TINY, center=torch.from_numpy(g['center']))
-    eng = Engine(TINY, max_batch=16, max_seq=640, max_images=48, max_new_tokens=32)
-    eng.load_state(st)
+    old = os.environ.get('ORC_DECODE_NORM')
+    os.environ['ORC_DECODE_NORM'] = request.param
+    try:
+        eng = Engine(TINY, max_batch=16, max_seq=640, max_images=48, max_new_tokens=32)
+        eng.load_state(st)
+    finally:
+        if old is None:
+            os.environ.pop('ORC_DECODE_NORM', None)
+        else:
+            os.environ['ORC_DECODE_NORM'] = old
     model = LlavaLlamaForCausalLM(LlavaConfig(TINY, tokenizer_padding_side='left'), eng)
     yield g, model
     eng.close()
