@@ -14,10 +14,18 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         if backend is None:   # ORC_DIST_BACKEND=gloo: rehearsal with several ranks sharing one GPU (RCCL wants one GPU per rank)
             backend = os.environ.get('ORC_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
-        if backend == 'nccl':
-            torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
-        dist.init_process_group(backend)
+        if backend == 'nccl':   # one init path for RCCL (bench.py uses it too): the rank's GPU is bound to the group at creation
+            local = int(os.environ.get('LOCAL_RANK', 0))
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend)
     return rank, world
+
+
+def collective_device():
+    """Where tensors of a collective must live: the rank's GPU under RCCL, the host under gloo."""
+    return torch.device('cuda', torch.cuda.current_device()) if dist.is_initialized() and dist.get_backend() == 'nccl' else torch.device('cpu')
 
 
 def finalize():
@@ -56,13 +64,34 @@ def gather_token_ids(tokens, lengths, world):
     return out
 
 
-def gather_objects(obj, rank, world):
-    """Merge per-rank {scan_id: predictions} dicts on rank 0 (host-side, used by the CLI)."""
-    if world == 1:
-        return obj
-    parts = [None] * world
-    dist.all_gather_object(parts, obj)
-    merged = {}
-    for p in parts:
-        merged.update(p)
-    return merged
+def rows_per_rank(n, world, groups=None):
+    """Rows of the fixed-shape gather buffer: the largest shard (uneven shards -- 1378 frames over 8 ranks, or whole takes of
+    different sizes -- are padded with length-0 rows)."""
+    return max(len(shard_indices(n, r, world, groups)) for r in range(world)) if n else 0
+
+
+def pack_token_rows(token_lists, n_rows, max_new):
+    """This rank's answers, one per frame of its shard in shard order (lists of new-token ids), as the [n_rows, 1 + max_new] int32
+    buffer of SURVEY 8e: column 0 = number of tokens (0 for the padding rows of a short shard), then the ids, zero-filled."""
+    assert len(token_lists) <= n_rows
+    toks = torch.zeros(n_rows, max_new, dtype=torch.int32)
+    lens = torch.zeros(n_rows, dtype=torch.int32)
+    for j, ids in enumerate(token_lists):
+        ids = list(ids)[:max_new]
+        lens[j] = len(ids)
+        if ids:
+            toks[j, :len(ids)] = torch.tensor(ids, dtype=torch.int32)
+    return toks, lens
+
+
+def unpack_token_rows(allbuf, n, world, groups=None):
+    """The all-gathered [world * n_rows, 1 + max_new] buffer -> {frame index: list of token ids} over the whole split (row j of
+    rank r's block is frame shard_indices(n, r, world, groups)[j])."""
+    allbuf = allbuf.cpu()
+    n_rows = allbuf.shape[0] // world
+    out = {}
+    for r in range(world):
+        for j, idx in enumerate(shard_indices(n, r, world, groups)):
+            row = allbuf[r * n_rows + j]
+            out[idx] = row[1:1 + int(row[0])].tolist()
+    return out

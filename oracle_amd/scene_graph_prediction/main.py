@@ -18,6 +18,7 @@ import torch
 from .scene_graph_helpers.dataset.synthetic_dataset import SyntheticORDataset, batches
 from .scene_graph_helpers.model.scene_graph_prediction_model_oracle import OracleWrapper
 
+MAX_NEW_TOKENS = 300   # the reference's generate(max_new_tokens=300) (..._oracle.py:135-143): width of the gathered token buffer
 CONFIG_DIRS = [Path('scene_graph_prediction/scene_graph_helpers/configs'), Path(__file__).parent / 'scene_graph_helpers' / 'configs']
 
 
@@ -75,13 +76,30 @@ def main(argv=None):
     takes = [int(s.split('_')[0]) for s in eval_dataset.scans]
     mine = parallel.shard_indices(len(eval_dataset), rank, world, groups=takes if temporal else None)
     results = model.validate(batches(eval_dataset, batch_size, mine), return_raw_predictions=True, report=world == 1)
-    results = parallel.gather_objects(results, rank, world)
     if world > 1:
-        # every rank saw only its shard: merge the per-frame labels and print the reference's reports ONCE, on rank 0,
-        # over the whole split (N partial reports are not the metric the reference prints)
-        frame_rel = parallel.gather_objects(model.last_frame_rel, rank, world)
+        # the ONLY exchange of the multi-GPU path is one all-gather (RCCL over xGMI) of a fixed-shape int32 buffer
+        # [frames per rank, 1 + 300] -- the answer's length, then its token ids, length 0 for the padding rows of a short shard.
+        # Every rank saw only its shard; rank 0 detokenises, parses and scores the whole split in dataset order and prints the
+        # reference's per-take and overall reports ONCE (N partial reports are not the metric the reference prints).
+        import torch.distributed as dist
+        groups = takes if temporal else None
+        n = len(eval_dataset)
+        n_rows = parallel.rows_per_rank(n, world, groups)
+        toks, lens = parallel.pack_token_rows([model.last_new_tokens[eval_dataset.scans[i]] for i in mine], n_rows, MAX_NEW_TOKENS)
+        dev = parallel.collective_device()
+        allbuf = parallel.gather_token_ids(toks.to(dev), lens.to(dev), world)
+        results = None
         if rank == 0:
-            model.report_merged(frame_rel, eval_dataset.scans)
+            rows = parallel.unpack_token_rows(allbuf, n, world, groups)
+            # a frame generated in a one-frame batch keeps its special tokens in the string (forward(), reference :144-147):
+            # the temporal variant always, otherwise the last frame of a shard whose size is 1 mod the batch size
+            single = {}
+            for r in range(world):
+                shard = parallel.shard_indices(n, r, world, groups)
+                for j, idx in enumerate(shard):
+                    single[idx] = batch_size == 1 or (len(shard) % batch_size == 1 and j == len(shard) - 1)
+            results = model.score_token_ids([eval_dataset[i] for i in range(n)], [rows[i] for i in range(n)], [single[i] for i in range(n)])
+        dist.barrier()
     if args.mode == 'infer' and rank == 0:
         out = f'scan_relations_{name}_{split}.json'
         with open(out, 'w') as f:

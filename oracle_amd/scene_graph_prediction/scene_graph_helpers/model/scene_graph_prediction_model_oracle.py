@@ -55,6 +55,7 @@ class OracleWrapper:
         # decoder releases the GIL). 0 = decode in the main thread at use, as the reference does.
         self.decode_workers = min(8, max(1, (os.cpu_count() or 2) // 2)) if decode_workers is None else int(decode_workers)
         self._pool = None
+        self.last_new_tokens = {}       # scan_id -> token ids of the answer (what a multi-GPU run all-gathers: oracle_amd/parallel.py)
         self.temporal_online_prediction = config.get('temporality') == 'PRED'
         if self.temporal_online_prediction:
             print('Preparing temporality PRED')
@@ -180,10 +181,23 @@ class OracleWrapper:
     def _finish(self, batch, input_ids, output_ids):
         """Host side of forward() after generate(): token ids -> strings (+ symbolic back-map)."""
         new = output_ids[:, input_ids.shape[1]:]
-        if len(batch) == 1:
-            outputs = [self.tokenizer.decode(new[0]).strip()]
+        rows = new.tolist()
+        pad = self.tokenizer.pad_token_id
+        for elem, ids in zip(batch, rows):     # what the multi-GPU path exchanges (oracle_amd/parallel.py): the answer's token ids
+            n = len(ids)
+            while n > 0 and ids[n - 1] == pad:
+                n -= 1
+            self.last_new_tokens[elem['scan_id']] = ids[:n]
+        return self.outputs_from_token_ids(rows, single=len(batch) == 1)
+
+    def outputs_from_token_ids(self, rows, single):
+        """Token ids of the answers -> the strings forward() returns (reference ..._oracle.py:144-166): one-frame batches keep
+        special tokens (`tokenizer.decode(ids).strip()`), larger ones drop them; symbolic back-map where the model uses symbols.
+        Trailing pad of a finished row changes neither form for the parser (pad is a special token / stripped with the tags)."""
+        if single:
+            outputs = [self.tokenizer.decode(torch.as_tensor(r)).strip() for r in rows]
         else:
-            outputs = self.tokenizer.batch_decode(new.tolist(), skip_special_tokens=True)
+            outputs = self.tokenizer.batch_decode([list(r) for r in rows], skip_special_tokens=True)
         if self._is_symbolic() or self.config['USE_VIS_DESC']:
             outputs = [self.symbols_to_names(o) for o in outputs]
         return outputs
@@ -310,44 +324,53 @@ class OracleWrapper:
         for batch, outputs in run():
             assert len(batch) == 1 or not self.temporal_online_prediction
             for elem, output in zip(batch, outputs):
-                timepoint = int(elem['scan_id'].split('_')[1])
-                take_idx = elem['take_idx']
-                raw, triplets, humans = self.parse_answer(output)
-                scan_id_to_raw_predictions[elem['scan_id']] = raw
-                if self.temporal_online_prediction:
-                    self.take_to_history[take_idx].append({'timepoint_idx': timepoint, 'scene_graph': raw})
-                role_to_human = {role: f'human_{i}' for i, role in enumerate(sorted(humans))}
-                rel_preds = []
-                for sub, pred, obj in triplets:
+                self._score_frame(elem, output, take_rel_preds, take_rel_gts, frame_rel, scan_id_to_raw_predictions, none_id)
+        return self._close_validation(take_rel_preds, take_rel_gts, frame_rel, scan_id_to_raw_predictions, report, logging_information,
+                                      return_raw_predictions)
+
+    def _score_frame(self, elem, output, take_rel_preds, take_rel_gts, frame_rel, scan_id_to_raw_predictions, none_id, keep_history=True):
+        """One answer string -> raw triplets, relation labels against the frame's ground truth (reference ..._oracle.py:261-342)."""
+        timepoint = int(elem['scan_id'].split('_')[1])
+        take_idx = elem['take_idx']
+        raw, triplets, humans = self.parse_answer(output)
+        scan_id_to_raw_predictions[elem['scan_id']] = raw
+        if self.temporal_online_prediction and keep_history:
+            self.take_to_history[take_idx].append({'timepoint_idx': timepoint, 'scene_graph': raw})
+        role_to_human = {role: f'human_{i}' for i, role in enumerate(sorted(humans))}
+        rel_preds = []
+        for sub, pred, obj in triplets:
+            try:
+                rel_preds.append((map_scene_graph_name_to_vocab_idx(role_to_human.get(sub, sub).replace(' ', '_')),
+                                  map_scene_graph_name_to_vocab_idx(pred),
+                                  map_scene_graph_name_to_vocab_idx(role_to_human.get(obj, obj).replace(' ', '_'))))
+            except Exception as e:   # unknown entity / predicate names are dropped, as in the reference
+                print(e)
+        # the reference maps (sub, pred, obj) -> indices in the order (sub, pred, obj); keep that tuple order
+        rel_labels = torch.tensor(elem['relations_tokenized'])
+        hmap = self.compute_optimal_human_indices(rel_preds, rel_labels)
+        rel_preds = [(hmap.get(s, s), r, hmap.get(o, o)) for s, r, o in rel_preds]
+        labels = rel_labels.tolist()
+        gt_objects = sorted({x for s, _, o in labels for x in (s, o)}) if labels else []
+        n0 = len(take_rel_gts[take_idx])
+        for a in gt_objects:
+            for b in gt_objects:
+                if a == b:
+                    continue
+                gt_rel = next((r for s, r, o in labels if s == a and o == b), None)
+                take_rel_gts[take_idx].append(none_id if gt_rel is None else
+                                              self.relation_names_lower_case.index(map_vocab_idx_to_scene_graph_name(gt_rel)))
+                pr = next((r for s, r, o in rel_preds if s == a and o == b), None)
+                if pr is None:
+                    take_rel_preds[take_idx].append(none_id)
+                else:
                     try:
-                        rel_preds.append((map_scene_graph_name_to_vocab_idx(role_to_human.get(sub, sub).replace(' ', '_')),
-                                          map_scene_graph_name_to_vocab_idx(pred),
-                                          map_scene_graph_name_to_vocab_idx(role_to_human.get(obj, obj).replace(' ', '_'))))
-                    except Exception as e:   # unknown entity / predicate names are dropped, as in the reference
-                        print(e)
-                # the reference maps (sub, pred, obj) -> indices in the order (sub, pred, obj); keep that tuple order
-                rel_labels = torch.tensor(elem['relations_tokenized'])
-                hmap = self.compute_optimal_human_indices(rel_preds, rel_labels)
-                rel_preds = [(hmap.get(s, s), r, hmap.get(o, o)) for s, r, o in rel_preds]
-                labels = rel_labels.tolist()
-                gt_objects = sorted({x for s, _, o in labels for x in (s, o)}) if labels else []
-                n0 = len(take_rel_gts[take_idx])
-                for a in gt_objects:
-                    for b in gt_objects:
-                        if a == b:
-                            continue
-                        gt_rel = next((r for s, r, o in labels if s == a and o == b), None)
-                        take_rel_gts[take_idx].append(none_id if gt_rel is None else
-                                                      self.relation_names_lower_case.index(map_vocab_idx_to_scene_graph_name(gt_rel)))
-                        pr = next((r for s, r, o in rel_preds if s == a and o == b), None)
-                        if pr is None:
-                            take_rel_preds[take_idx].append(none_id)
-                        else:
-                            try:
-                                take_rel_preds[take_idx].append(self.relation_names_lower_case.index(map_vocab_idx_to_scene_graph_name(pr)))
-                            except Exception:   # a nonsense relation counts as 'none'
-                                take_rel_preds[take_idx].append(none_id)
-                frame_rel[elem['scan_id']] = (take_idx, take_rel_preds[take_idx][n0:], take_rel_gts[take_idx][n0:])
+                        take_rel_preds[take_idx].append(self.relation_names_lower_case.index(map_vocab_idx_to_scene_graph_name(pr)))
+                    except Exception:   # a nonsense relation counts as 'none'
+                        take_rel_preds[take_idx].append(none_id)
+        frame_rel[elem['scan_id']] = (take_idx, take_rel_preds[take_idx][n0:], take_rel_gts[take_idx][n0:])
+
+    def _close_validation(self, take_rel_preds, take_rel_gts, frame_rel, scan_id_to_raw_predictions, report, logging_information,
+                          return_raw_predictions):
         self.last_frame_rel = frame_rel
         self.val_take_rel_preds, self.val_take_rel_gts = take_rel_preds, take_rel_gts
         self.last_take_rel = (dict(take_rel_preds), dict(take_rel_gts))
@@ -356,6 +379,20 @@ class OracleWrapper:
         self.reset_metrics(split='val')
         if return_raw_predictions:
             return scan_id_to_raw_predictions
+
+    def score_token_ids(self, elems, token_rows, single_flags, logging_information=None):
+        """Rank 0 of a multi-GPU run: the whole split's answers arrive as token ids (one RCCL all-gather, oracle_amd/parallel.py);
+        detokenise, back-map, parse and score them in dataset order and print the reference's per-take and overall reports --
+        what validate() does in one process. elems: the dataset items in dataset order; token_rows: their answers' token ids;
+        single_flags[i]: the frame was generated in a one-frame batch (its string keeps special tokens, as forward() returns it).
+        Returns {scan_id: raw triplets}."""
+        take_rel_preds, take_rel_gts = defaultdict(list), defaultdict(list)
+        frame_rel, raw_predictions = {}, {}
+        none_id = self.relation_names_lower_case.index('none')
+        for elem, ids, single in zip(elems, token_rows, single_flags):
+            output = self.outputs_from_token_ids([ids], single=single)[0]
+            self._score_frame(elem, output, take_rel_preds, take_rel_gts, frame_rel, raw_predictions, none_id, keep_history=False)
+        return self._close_validation(take_rel_preds, take_rel_gts, frame_rel, raw_predictions, True, logging_information, True)
 
     def report_merged(self, frame_rel, scan_order, logging_information=None):
         """Per-take and overall reports over per-frame labels gathered from all ranks ({scan_id: (take, preds, gts)}),

@@ -33,11 +33,10 @@ def _worker(rank, world, port, out):
         toks[j] = idx * 10 + torch.arange(5, dtype=torch.int32)
         lens[j] = 1 + idx % 5
     allbuf = parallel.gather_token_ids(toks, lens, w)
-    merged = parallel.gather_objects({f's{idx}': [idx] for idx in mine}, r, w)
     groups = [4] * 5 + [8] * 6
     tmine = parallel.shard_indices(n, r, w, groups=groups)
     if r == 0:
-        torch.save({'allbuf': allbuf, 'merged': merged, 'mine': mine, 'tmine': tmine}, out)
+        torch.save({'allbuf': allbuf, 'mine': mine, 'tmine': tmine}, out)
     dist.barrier()
     parallel.finalize()
 
@@ -55,9 +54,49 @@ def test_world2_sharding_and_gather(tmp_path):
             assert row[1:] == [idx * 10 + k for k in range(5)] and row[0] == 1 + idx % 5
             seen[idx] = True
     assert sorted(seen) == list(range(11))
-    assert sorted(res['merged']) == sorted(f's{i}' for i in range(11))
     assert res['mine'] == [0, 2, 4, 6, 8, 10]
     assert res['tmine'] == [5, 6, 7, 8, 9, 10]       # the larger take goes to rank 0, whole and in order
+
+
+def _worker_rows(rank, world, port, out, n, groups):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from oracle_amd import parallel
+    r, w = parallel.init_from_env(backend='gloo')
+    mine = parallel.shard_indices(n, r, w, groups)
+    answers = [[1000 * idx + k for k in range(idx % 7)] for idx in mine]          # ragged answers, some empty, one over-long
+    if mine:
+        answers[-1] = answers[-1] + list(range(400))
+    n_rows = parallel.rows_per_rank(n, w, groups)
+    toks, lens = parallel.pack_token_rows(answers, n_rows, 300)
+    dev = parallel.collective_device()
+    allbuf = parallel.gather_token_ids(toks.to(dev), lens.to(dev), w)
+    if r == 0:
+        torch.save({'allbuf': allbuf, 'rows': parallel.unpack_token_rows(allbuf, n, w, groups), 'n_rows': n_rows}, out)
+    dist.barrier()
+    parallel.finalize()
+
+
+def test_world2_token_rows_uneven_shards_and_takes(tmp_path):
+    """The product path's exchange (CLI: oracle_amd/scene_graph_prediction/main.py): [rows per rank, 1 + 300] int32, length-prefixed,
+    padding rows of the shorter shard have length 0; round-robin shards of 9 / 8 frames and take shards of 12 / 5."""
+    for case, (n, groups) in enumerate([(17, None), (17, [4] * 12 + [8] * 5), (1, None)]):
+        out = str(tmp_path / f'rows{case}.pt')
+        mp.spawn(_worker_rows, args=(2, _free_port(), out, n, groups), nprocs=2, join=True)
+        res = torch.load(out)
+        from oracle_amd.parallel import shard_indices
+        assert res['allbuf'].shape == (2 * res['n_rows'], 301) and res['allbuf'].dtype == torch.int32
+        assert res['n_rows'] == max(len(shard_indices(n, r, 2, groups)) for r in range(2))
+        assert sorted(res['rows']) == list(range(n))
+        for r in range(2):
+            shard = shard_indices(n, r, 2, groups)
+            for j, idx in enumerate(shard):
+                want = [1000 * idx + k for k in range(idx % 7)]
+                if j == len(shard) - 1:
+                    want = (want + list(range(400)))[:300]
+                assert res['rows'][idx] == want, (case, idx)
+            for j in range(len(shard), res['n_rows']):                             # padding rows: length 0
+                assert int(res['allbuf'][r * res['n_rows'] + j, 0]) == 0
 
 
 def test_shard_properties():
