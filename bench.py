@@ -274,6 +274,81 @@ def ragged_runs(model, input_ids, images, batch, n_batches, rank):
     return out
 
 
+SPLIT_FRAMES = 1378        # 4D-OR test split (reference helpers/configurations.py:46, data/relationships_test_dummy.json)
+SPLIT_CAMERAS = (2, 1, 3)  # of the 6 camera slots of a frame (configs/oracle_mv_learned.json CAMERAS, 1-based)
+
+
+def split_run(model, input_ids, a, rank, world, dev, dims, n_frames, compute=True):
+    """BASELINE configs[4]: the frame-sharded evaluation over a 1378-frame, 6-camera-slot synthetic split (the reference's loop
+    ..._oracle.py:251-260 over one process; here rank r takes frames r::world). Per rank: batches of a.batch frames through
+    generate_stream() (continuous batching) with the 4D-OR answer lengths as per-frame length stops; then ONE all-gather of the
+    fixed-shape int32 [frames per rank, 1 + 300] token buffer (uneven shards padded with length-0 rows; RCCL over xGMI under
+    'nccl'); rank 0 checks every frame arrived with its length. compute=False (--dry-run): scripted answers instead of the engine.
+    Returns (rank 0) whole-split frames/s over the slowest rank, per-rank busy seconds, gather milliseconds."""
+    import torch
+    import torch.distributed as dist
+    from oracle_amd import parallel
+    lens, _ = ragged_lengths(n_frames, 777, 300)                      # per FRAME index: the same for every world size
+    mine = parallel.shard_indices(n_frames, rank, world)
+    n_rows = parallel.rows_per_rank(n_frames, world)
+    batches_ = [mine[i:i + a.batch] for i in range(0, len(mine), a.batch)]
+    if compute:
+        from oracle_amd.synth import synth_images
+        pool = synth_images(16, 6, dims, seed=4321).to(dev)           # 16 distinct frames x 6 camera slots, reused round-robin
+        cams = [c - 1 for c in SPLIT_CAMERAS][:a.views]
+        items = [{'input_ids': input_ids[:len(b)], 'images': torch.stack([pool[i % 16][cams] for i in b]), 'limits': [lens[i] for i in b]}
+                 for b in batches_]
+        if a.views == 1:
+            for it in items:
+                it['images'] = it['images'][:, 0]
+    if world > 1:
+        dist.barrier()
+    if compute:
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    answers = []
+    if compute:
+        L = input_ids.shape[1]
+        for b, out in zip(batches_, model.generate_stream(iter(items), max_new_tokens=300, n_rows=a.split_rows or a.batch, chunk=8)):
+            new = out[:, L:].cpu()
+            for j, i in enumerate(b):
+                answers.append(new[j, :lens[i]].tolist() if new.shape[1] >= lens[i] else new[j].tolist())
+        torch.cuda.synchronize()
+    else:
+        for b in batches_:
+            time.sleep(0.002 * len(b) * (rank + 1))
+            answers.extend([[7 + i % 5] * lens[i] for i in b])
+    busy = time.perf_counter() - t0
+    g0 = time.perf_counter()
+    toks, lens_t = parallel.pack_token_rows(answers, n_rows, 300)
+    cdev = parallel.collective_device()
+    allbuf = parallel.gather_token_ids(toks.to(cdev), lens_t.to(cdev), world)
+    if cdev.type == 'cuda':
+        torch.cuda.synchronize()
+    gather_ms = (time.perf_counter() - g0) * 1e3
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    stats = torch.tensor([elapsed, busy, gather_ms], dtype=torch.float64, device=cdev)
+    if world > 1:
+        every = torch.empty(world * 3, dtype=torch.float64, device=cdev)
+        dist.all_gather_into_tensor(every, stats)
+        every = every.cpu().view(world, 3)
+    else:
+        every = stats.cpu().view(1, 3)
+    if rank != 0:
+        return None
+    rows = parallel.unpack_token_rows(allbuf, n_frames, world)
+    ok = sorted(rows) == list(range(n_frames)) and all(len(rows[i]) == lens[i] for i in range(n_frames))
+    wall = float(every[:, 0].max())
+    return {'workload': f'BASELINE configs[4]: {n_frames}-frame split (4D-OR test split: {SPLIT_FRAMES}), 6 camera slots of which {a.views}, frames '
+                        f'r::{world}, batches of {a.batch}, generate_stream ({a.split_rows or a.batch} decode rows), 4D-OR answer lengths, one final all-gather',
+            'frames': n_frames, 'world_size': world, 'frames_per_rank': [len(parallel.shard_indices(n_frames, r, world)) for r in range(world)],
+            'frames_per_s': n_frames / wall, 'seconds': wall, 'per_rank_busy_s': [float(x) for x in every[:, 1]],
+            'gather_ms': float(every[:, 2].max()), 'gather_buffer': [world * n_rows, 301], 'mean_len': sum(lens) / len(lens),
+            'tokens_emitted': sum(len(r) for r in rows.values()), 'all_frames_arrived_with_their_length': ok}
+
+
 def launch_ranks(n):
     """`bench.py --gpus N` without an external launcher: this parent process never touches a GPU (no torch import); it
     starts N fresh ranks through torch.distributed.run on the loopback address and passes rank 0's JSON line through."""
@@ -310,9 +385,10 @@ def dry_run(a):
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    split = split_run(None, None, a, rank, world, None, None, a.split_frames if a.split_frames is not None else 45, compute=False)
     if rank == 0:
         print(json.dumps({'dry_run': True, 'n_gpus': world, 'steps': a.steps, 'frames': world * a.steps * a.batch,
-                          'ms_per_step': float(t) / a.steps * 1e3, 'slowest_rank_floor_ms': 10.0 * world}), flush=True)
+                          'ms_per_step': float(t) / a.steps * 1e3, 'slowest_rank_floor_ms': 10.0 * world, 'extra': {'split': split}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -333,6 +409,10 @@ def main():
                     help="'both' (default): after the uniform-length headline also run the 4D-OR answer-length distribution "
                          "(extra.ragged: batch-by-batch vs slot refill); 'uniform': headline only")
     ap.add_argument('--ragged-batches', type=int, default=16)
+    ap.add_argument('--split-frames', type=int, default=None,
+                    help='frames of the sharded-split leg (extra.split, BASELINE configs[4]); default: the whole 1378-frame split when '
+                         '--gpus > 1, a quarter of it (344) on one GPU so that the default run stays within minutes; 0 skips the leg')
+    ap.add_argument('--split-rows', type=int, default=None, help='decode rows of the split leg (default: --batch, the reference\'s batch size)')
     ap.add_argument('--cpu-point', action='store_true',
                     help='time BASELINE configs[0] for real on the host cores (full-size fp32 CPU oracle, ~30 GB RAM, ~1 min) and exit')
     ap.add_argument('--eager-point', action='store_true',
@@ -453,6 +533,12 @@ def main():
     ragged = None
     if rank == 0 and a.lengths == 'both' and a.batch > 1:
         ragged = ragged_runs(model, input_ids, images, a.batch, a.ragged_batches, rank)
+    split = None
+    n_split = a.split_frames if a.split_frames is not None else (SPLIT_FRAMES if world > 1 else SPLIT_FRAMES // 4)
+    if a.lengths == 'both' and n_split > 0:      # every rank takes part (collective inside)
+        if world > 1 and backend != 'nccl':
+            pass                                  # gloo rehearsal: parallel.collective_device() follows the group's backend
+        split = split_run(model, input_ids, a, rank, world, dev, dims, n_split)
     check = None
     if rank == 0 and a.batch > 1 and not a.no_self_check:
         check = self_check(model, eng, input_ids, images, new)
@@ -517,6 +603,8 @@ def main():
             'note': 'a matrix that cannot take the 12-bit stream keeps bf16 and is reported on stderr at orc_engine_finalize'}
         if ragged is not None:
             res['extra'] = {'ragged': ragged}
+        if split is not None:
+            res.setdefault('extra', {})['split'] = split
         eager = os.path.join(ROOT, 'profiles', 'r2', 'eager_gpu_point.json')
         if os.path.exists(eager) and a.dims == 'full':   # a recorded point (python bench.py --eager-point), not measured in this run
             res.setdefault('extra', {})['reference_stack_on_mi355x'] = dict(json.load(open(eager))['eager_gpu_point'], source='profiles/r2/eager_gpu_point.json',

@@ -129,6 +129,10 @@ def test_bench_launches_its_own_ranks_and_checks_world_size():
     res = json.loads(lines[0])
     assert res['n_gpus'] == 2 and res['frames'] == 2 * 3 * 8
     assert res['ms_per_step'] >= res['slowest_rank_floor_ms']          # the slowest rank (rank 1 sleeps 20 ms) sets the time
+    sp = res['extra']['split']                                         # the config-5 leg: sharded split, uneven shards, one final gather
+    assert sp['frames'] == 45 and sp['frames_per_rank'] == [23, 22] and sp['gather_buffer'] == [46, 301]
+    assert sp['all_frames_arrived_with_their_length'] and len(sp['per_rank_busy_s']) == 2
+    assert sp['seconds'] >= max(sp['per_rank_busy_s'])                  # whole-split time = the slowest rank + the gather
     env2 = dict(env, WORLD_SIZE='4', RANK='0')
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--dry-run'], capture_output=True, text=True,
                        timeout=60, env=env2)
