@@ -104,15 +104,31 @@ def cpu_baseline(new_tokens, views, prompt_len_spliced):
         real = {'source': os.path.relpath(pts[-1], ROOT), 'seconds_per_frame': real['seconds_per_frame'], 'cores': real['cores'],
                 'config': real['config'],
                 'same_method_estimate_for_that_config_s': t_clip2 / 2 * 23 + (t_pre1 - t_head) * L + t_head + 32 * ((t_dec1 - t_head) * L + t_head)}
-    return {'value': 1.0 / per_frame, 'unit': 'frames/s', 'cores': cores, 'kind': 'port', 'measured_full_size_point': real,
-            'sample': (f'fp32 CPU oracle, 1 frame: CLIP 1 view x 2 layers ({t_clip2:.2f}s) scaled to {views} views x 23 layers; '
-                       f'pooler+projector ({t_pool:.2f}s); 1 LLaMA layer prefill T={prompt_len_spliced} ({t_pre1:.2f}s) x32; '
-                       f'1 layer decode step ({t_dec1 * 1e3:.0f}ms incl. lm_head {t_head * 1e3:.0f}ms) x32 x {new_tokens} tokens'),
-            's_per_frame': per_frame}
+    sample = (f'fp32 CPU oracle, 1 frame: CLIP 1 view x 2 layers ({t_clip2:.2f}s) scaled to {views} views x 23 layers; '
+              f'pooler+projector ({t_pool:.2f}s); 1 LLaMA layer prefill T={prompt_len_spliced} ({t_pre1:.2f}s) x32; '
+              f'1 layer decode step ({t_dec1 * 1e3:.0f}ms incl. lm_head {t_head * 1e3:.0f}ms) x32 x {new_tokens} tokens')
+    out = {'value': 1.0 / per_frame, 'unit': 'frames/s', 'cores': cores, 'kind': 'port', 'measured': False, 'measured_full_size_point': real,
+           'sample': sample, 's_per_frame': per_frame}
+    # the headline workload measured END TO END once (python bench.py --cpu-point --cpu-config 2: one whole frame, full size, all host
+    # threads; committed record): that measurement is the baseline the line cites; the bounded live sample above (the contract's
+    # 10-30 s of CPU work in every run) stays beside it as a same-box sanity ratio
+    recs = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*', 'cpu_point_configs2.json')))
+    if recs:
+        m = json.load(open(recs[-1]))['cpu_point']
+        if m.get('views') == views and m.get('new_tokens') == new_tokens:
+            out.update({'value': m['frames_per_s'], 's_per_frame': m['seconds_per_frame'], 'measured': True, 'source': os.path.relpath(recs[-1], ROOT),
+                        'cores': m['cores'], 'torch_threads': m.get('torch_threads'), 'host_cpus': m.get('host_cpus'),
+                        'sample': 'MEASURED: ' + m['config'] + f' ({m["seconds_per_frame"]:.1f} s: vision {m["vision_s"]:.1f} s, prefill + decode {m["prefill_plus_decode_s"]:.1f} s)',
+                        'live_bounded_sample': {'s_per_frame_estimate': per_frame, 'cores': cores, 'ratio_to_measured': per_frame / m['seconds_per_frame'],
+                                                'what': sample}})
+    return out
 
 
-def cpu_point():
-    """BASELINE configs[0], timed for real (BASELINE.md 3 "the mandatory CPU point"): single-view LLaVA-1.5-7B
+def cpu_point(config=0, new_tokens=None):
+    """config 2 (python bench.py --cpu-point --cpu-config 2): ONE frame of the headline workload (BASELINE configs[2]: 3 views,
+    learned pooler, plain prompt, 150-token greedy decode) through the same full-size fp32 CPU oracle, ~2 minutes on 16 cores;
+    its record under profiles/ is what the default run's `cpu_baseline` cites (measured: true).
+    config 0: BASELINE configs[0], timed for real (BASELINE.md 3 "the mandatory CPU point"): single-view LLaVA-1.5-7B
     (mv_type=concat), one synthetic 336x336 frame, the plain ORacle prompt, 32-token greedy decode, through the fp32 CPU
     oracle (oracle/cpu_ref.py) at FULL size on all host threads. Needs ~30 GB of RAM and about a minute; not part of the
     default run (python bench.py --cpu-point)."""
@@ -125,17 +141,20 @@ def cpu_point():
     t0 = time.perf_counter()
     st = synth.synth_state(FULL, seed=0, dtype=torch.float32, device='cpu', device_fast=True)
     t_w = time.perf_counter() - t0
-    ids, images = build_inputs(SynthTokenizer(FULL.vocab), 1, 1, FULL, 'cpu')
+    views, mv = (3, 'learned') if config == 2 else (1, 'concat')
+    n_new = new_tokens or (150 if config == 2 else 32)
+    ids, images = build_inputs(SynthTokenizer(FULL.vocab), 1, views, FULL, 'cpu')
     with torch.inference_mode():
         t0 = time.perf_counter()
-        feats = cr.encode_image_features(st, FULL, images.float(), 'concat')
+        feats = cr.encode_image_features(st, FULL, images.float(), mv)
         t_vis = time.perf_counter() - t0
         t0 = time.perf_counter()
-        out = cr.greedy_generate(st, FULL, ids, None, mv_type='concat', max_new_tokens=32, eos_token_id=-1, image_features=feats)
+        out = cr.greedy_generate(st, FULL, ids, None, mv_type=mv, max_new_tokens=n_new, eos_token_id=-1, image_features=feats)
         t_gen = time.perf_counter() - t0
     n = out.shape[1] - ids.shape[1]
-    res = {'config': 'BASELINE configs[0]: single-view LLaVA-1.5-7B, 1 synthetic 336x336 frame, plain prompt '
-                     f'(spliced T={ids.shape[1] - 1 + 576}), {n}-token greedy decode, fp32 CPU oracle, full size',
+    res = {'config': (f'BASELINE configs[{config}]: ' + ('single-view LLaVA-1.5-7B' if config != 2 else '3-view ORacle LLaVA-7B (learned pooler), ONE frame of the batch-8 headline step')
+                      + f', synthetic 336x336 views, plain prompt (spliced T={ids.shape[1] - 1 + 576}), {n}-token greedy decode, fp32 CPU oracle, full size'),
+           'baseline_config': config, 'views': views, 'torch_threads': torch.get_num_threads(), 'host_cpus': os.cpu_count(),
            'cores': torch.get_num_threads(), 'seconds_per_frame': t_vis + t_gen, 'frames_per_s': 1.0 / (t_vis + t_gen),
            'vision_s': t_vis, 'prefill_plus_decode_s': t_gen, 'random_weight_generation_s': t_w, 'new_tokens': n}
     print(json.dumps({'cpu_point': res}), flush=True)
@@ -415,6 +434,7 @@ def main():
     ap.add_argument('--split-rows', type=int, default=None, help='decode rows of the split leg (default: --batch, the reference\'s batch size)')
     ap.add_argument('--cpu-point', action='store_true',
                     help='time BASELINE configs[0] for real on the host cores (full-size fp32 CPU oracle, ~30 GB RAM, ~1 min) and exit')
+    ap.add_argument('--cpu-config', type=int, default=0, choices=[0, 2], help='--cpu-point: BASELINE config to time (2 = one frame of the headline workload)')
     ap.add_argument('--eager-point', action='store_true',
                     help="time the same workload through the oracle's torch code run eager on the GPU (what the reference's stack does) and exit")
     ap.add_argument('--dry-run', action='store_true',
@@ -430,7 +450,7 @@ def main():
     if a.dry_run:
         return dry_run(a)
     if a.cpu_point:
-        return cpu_point()
+        return cpu_point(a.cpu_config)
     if a.eager_point:
         return eager_gpu_point(a)
 
