@@ -172,7 +172,7 @@ def select_chain_layout(n_dirs=SELECT_DIRS, base=CHAIN_BASE, stride=SELECT_CHAIN
     return [(base + k * stride, base + k * stride + 5 + 3 * k) for k in range(2 * n_dirs)]
 
 
-def install_select_chains(state, d: Dims, center=None, n_dirs=SELECT_DIRS, g_sel=60.0, logit=60.0, boost=12.0, seed=77):
+def install_select_chains(state, d: Dims, center=None, n_dirs=SELECT_DIRS, g_sel=60.0, logit=60.0, boost=12.0, seed=77, dirs=None):
     """Greedy decoding whose answer is SELECTED BY THE IMAGE: with the <image> placeholder as the last
     prompt token, the final hidden state of the prefill is the LLaMA image of the last pooled + projected image-token row,
     i.e. ~70 % of it varies from frame to frame. lm_head rows of the 2*n_dirs chain-start tokens get +-g_sel along n_dirs
@@ -183,26 +183,38 @@ def install_select_chains(state, d: Dims, center=None, n_dirs=SELECT_DIRS, g_sel
     and ends with EOS, so rows of a batch finish at different steps. Chain-token embeddings are made orthogonal to the
     r_j, and their boost keeps the selection rows quiet at the later positions. `center` (d_model floats) is the mean of
     that hidden state over a few calibration frames (computed by the test infrastructure and stored with the golden
-    vectors); the r_j are made orthogonal to it so the frame-independent part does not decide the argmax."""
+    vectors); the r_j are made orthogonal to it so the frame-independent part does not decide the argmax.
+    `dirs` (K <= 2 * n_dirs rows of d_model floats): CALIBRATED directions instead of random ones -- chain k starts where
+    <h, dirs[k]> is largest (no +- pairs). With dirs[k] = the displacement of image class k's mean hidden state from the
+    centre, the whole signal lies along the direction while rounding noise is spread over d_model dims: the first-token
+    margin is then far above the noise of a 32-layer bf16 stack (tests/test_full_size_gpu.py: the 99 % identity rate)."""
     import math
     emb = state['model.embed_tokens.weight'].float()
     w = state['lm_head.weight'].float()
     dm = d.d_model
-    r = torch.from_numpy(_philox_normal(seed, 'select_dirs', (n_dirs, dm)))
+    r = torch.from_numpy(_philox_normal(seed, 'select_dirs', (n_dirs, dm))) if dirs is None else torch.as_tensor(dirs, dtype=torch.float32).clone()
     if center is not None:
         c = torch.as_tensor(center, dtype=torch.float32)
         c = c / c.norm()
         r = r - (r @ c)[:, None] * c
+    if dirs is not None:
+        assert r.shape[0] <= 2 * n_dirs and r.shape[1] == dm
+        start = r / r.norm(dim=-1, keepdim=True)                       # chain-start rows: the class displacements themselves (centre removed)
     r = torch.linalg.qr(r.T).Q.T.contiguous()                          # orthonormal rows (still orthogonal to center)
     g = logit / math.sqrt(dm)
     for k, (lo, hi) in enumerate(select_chain_layout(n_dirs)):
+        if dirs is not None and k >= start.shape[0]:
+            break
         u = emb[lo:hi + 1]
         u = u - (u @ r.T) @ r                                           # orthogonal to the selection directions
         u = u / u.norm(dim=-1, keepdim=True)
         emb[lo:hi + 1] = u * (boost * math.sqrt(dm))
         w[lo + 1:hi + 1] += g * u[:-1]                                  # v -> v + 1 inside the chain
         w[2] += g * u[-1]                                               # last token of the chain -> EOS
-        w[lo] += (g_sel if k % 2 == 0 else -g_sel) * r[k // 2]          # chain start: +- <h, r_j>
+        if dirs is not None:
+            w[lo] += g_sel * start[k]                                   # chain start: <h, class-k displacement>
+        else:
+            w[lo] += (g_sel if k % 2 == 0 else -g_sel) * r[k // 2]      # chain start: +- <h, r_j>
     state['model.embed_tokens.weight'] = emb.to(state['model.embed_tokens.weight'].dtype)
     state['lm_head.weight'] = w.to(state['lm_head.weight'].dtype)
     return state

@@ -15,10 +15,28 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN
+from conftest import GOLDEN, rms_rel_rows
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-2
+# RMS bar: r(x) = ||x - fp32 math||_2 / ||fp32 math||_2 per row (each row normalised by itself, so a
+# small-magnitude row cannot hide behind a large one) -- an average over every compared logit instead of the luck of the
+# worst one. The real reference's own bf16 run has r = 0.012-0.016 at this width (both of its runs are in the golden file),
+# i.e. the literal 1e-2 is below the reference's own rounding noise in this norm too; the bar is therefore relative to it,
+# per batch and step: (i) mean over the rows of r(GPU) <= RMS_FACTOR x mean over the rows of r(reference bf16);
+# (ii) EVERY (row, step) r(GPU) <= RMS_FACTOR x the largest r(reference bf16) over the rows and steps of the same golden case:
+# no GPU row is further from exact math than 1.1 x the reference's worst row. (A row's rounding noise is one random draw per
+# implementation: the reference's own rows spread 0.0115-0.0159 within one batch and step, the row-by-row ratio GPU /
+# reference was measured at 0.85-1.25 over 16 rows x 9 steps and the ratio of the two per-step maxima at 0.9-1.104 over 8
+# rows, so same-row and same-step ratios are ratios of two draws: printed, not asserted.)
+# On the golden subsample (every 97th logit, what the fixture holds) and, where the exact logits are recomputed on the card
+# (b8 / b16), over ALL 32000 logits.
+RMS_FACTOR = 1.1
+
+
+def _rms_bar(r_gpu, r_ref, what, ref_worst=None):
+    assert float(r_gpu.mean()) <= RMS_FACTOR * float(r_ref.mean()), (what, r_gpu, r_ref)
+    assert float(r_gpu.max()) <= RMS_FACTOR * (float(r_ref.max()) if ref_worst is None else ref_worst), (what, r_gpu, r_ref, ref_worst)
 
 
 @pytest.fixture(scope='module')
@@ -31,16 +49,15 @@ def wide():
     st = synth_state(d, seed=11)
     eng = Engine(d, max_batch=16, max_seq=2176, max_images=48, max_new_tokens=16)
     eng.load_state(st)
-    del st
     model = LlavaLlamaForCausalLM(LlavaConfig(d, tokenizer_padding_side='left'), eng)
-    yield d, eng, model
+    yield d, eng, model, st
     eng.close()
 
 
 @pytest.mark.parametrize('tag', ['b2', 'long'])
 def test_full_width_llama_against_reference_golden(wide, tag):
     from oracle_amd.synth import synth_images
-    d, eng, model = wide
+    d, eng, model, _ = wide
     g = np.load(os.path.join(GOLDEN, 'llm_wide_bfloat16.npz'))
     ids = torch.from_numpy(g[f'{tag}.ids'])
     imgs = synth_images(ids.shape[0], 3, d, seed=555)
@@ -59,6 +76,11 @@ def test_full_width_llama_against_reference_golden(wide, tag):
     print(f'{tag}: reference bf16 noise floor {floor:.4f}, GPU vs reference {err:.4f}, GPU vs fp32 math {err_exact:.4f}')
     assert err <= band, (err, floor)
     assert err_exact <= band, (err_exact, floor)
+    # RMS statistic, per row, on the fixture's subsample: the GPU is no further from exact math than the reference's bf16 run
+    rms_gpu, rms_ref = rms_rel_rows(logits[:, ::97], exact), rms_rel_rows(gold, exact)
+    print(f'{tag}: per-row RMS-relative error vs fp32 math: GPU {[round(float(x), 5) for x in rms_gpu]}, reference bf16 '
+          f'{[round(float(x), 5) for x in rms_ref]} (worst ratio {float((rms_gpu / rms_ref).max()):.3f})')
+    _rms_bar(rms_gpu, rms_ref, tag)
     # the reference's 16 best tokens keep their values
     idx = torch.from_numpy(g[f'{tag}.top16_idx'])
     val = torch.from_numpy(g[f'{tag}.top16_val'])
@@ -82,11 +104,32 @@ def test_full_width_headline_decode_path_8_and_16_rows(wide, tag):
     own bf16-vs-fp32 noise floor x 1.5 (never below the north_star's 1e-2), against both its bf16 and its fp32 logits;
     the reference's greedy token must be the GPU argmax unless its margin is inside the band."""
     from oracle_amd.synth import synth_images
-    d, eng, model = wide
+    from oracle import cpu_ref as cr
+    d, eng, model, st = wide
     g = np.load(os.path.join(GOLDEN, 'llm_wide_batch_bfloat16.npz'))
     ids = torch.from_numpy(g[f'{tag}.ids'])
     B = ids.shape[0]
     imgs = synth_images(B, 3, d, seed=600 + B)
+    # ALL logits of every step in exact (fp32) math and in eager bf16: the oracle's torch code executed on the card along the
+    # reference's tokens (the fixture holds every 97th logit of the real reference; fp32 math does not depend on the BLAS)
+    path = torch.from_numpy(g[f'{tag}.generated'])[:, ids.shape[1]:]
+    dev = torch.device('cuda', 0)
+    with torch.inference_mode(), torch.device(dev):
+        st32 = {k: v.to(dev).float() for k, v in st.items()}
+        _, tr32 = cr.greedy_generate(st32, d, ids.to(dev), imgs.to(dev).float(), max_new_tokens=path.shape[1], eos_token_id=-1,
+                                     forced_tokens=path.to(dev), return_trace=True, trace_logits_stride=1)
+        del st32
+        st16 = {k: v.to(dev) for k, v in st.items()}
+        _, tr16 = cr.greedy_generate(st16, d, ids.to(dev), imgs.to(dev), max_new_tokens=path.shape[1], eos_token_id=-1,
+                                     forced_tokens=path.to(dev), return_trace=True, trace_logits_stride=1)
+        del st16
+    full32 = [t['logits_sub'].float().cpu() for t in tr32]
+    full16 = [t['logits_sub'].float().cpu() for t in tr16]
+    del tr32, tr16
+    torch.cuda.empty_cache()
+    ref_worst = float(torch.stack([rms_rel_rows(torch.from_numpy(g[f'{tag}.logits_sub'])[:, i], torch.from_numpy(g[f'{tag}.logits_sub_fp32'])[:, i])
+                                   for i in range(path.shape[1])]).max())
+    rms_worst = {'sub_ratio': 0.0, 'all_ratio': 0.0, 'mean_ratio': 0.0, 'max_ratio': 0.0, 'gpu_all': 0.0, 'ref_sub': 0.0, 'eager_all': 0.0}
     mask = ids != 0
     pos = mask.long().cumsum(-1) - 1
     pos.masked_fill_(~mask, 1)
@@ -109,6 +152,20 @@ def test_full_width_headline_decode_path_8_and_16_rows(wide, tag):
         worst = max(worst, (err, err_exact, floor))
         assert err <= band, (tag, step, err, floor)
         assert err_exact <= band, (tag, step, err_exact, floor)
+        # the card's fp32 run reproduces the real reference's fp32 logits where the fixture has them (exact math is exact)
+        assert float((full32[step][:, ::97] - exact[:, step]).abs().max() / am.max()) < 2e-4, (tag, step)
+        # RMS per (row, step): on the fixture's subsample against the real reference, and over ALL logits against the fp32 math
+        r_gpu_sub, r_ref_sub = rms_rel_rows(cur[:, ::97], exact[:, step]), rms_rel_rows(gold[:, step], exact[:, step])
+        r_gpu_all, r_eager_all = rms_rel_rows(cur, full32[step]), rms_rel_rows(full16[step], full32[step])
+        rms_worst['sub_ratio'] = max(rms_worst['sub_ratio'], float((r_gpu_sub / r_ref_sub).max()))
+        rms_worst['all_ratio'] = max(rms_worst['all_ratio'], float((r_gpu_all / r_ref_sub).max()))
+        rms_worst['mean_ratio'] = max(rms_worst['mean_ratio'], float(r_gpu_all.mean() / r_ref_sub.mean()))
+        rms_worst['max_ratio'] = max(rms_worst['max_ratio'], float(max(r_gpu_all.max(), r_gpu_sub.max()) / ref_worst))
+        rms_worst['gpu_all'] = max(rms_worst['gpu_all'], float(r_gpu_all.max()))
+        rms_worst['ref_sub'] = max(rms_worst['ref_sub'], float(r_ref_sub.max()))
+        rms_worst['eager_all'] = max(rms_worst['eager_all'], float(r_eager_all.max()))
+        _rms_bar(r_gpu_sub, r_ref_sub, (tag, step, 'subsample'), ref_worst)
+        _rms_bar(r_gpu_all, r_ref_sub, (tag, step, 'all logits'), ref_worst)
         if step == 0:
             assert ((cur.gather(1, idx) - val).abs().max(-1).values / am).max().item() <= band
         tok = new[:, step]
@@ -119,6 +176,10 @@ def test_full_width_headline_decode_path_8_and_16_rows(wide, tag):
             cur = eng.decode_step(tok.cuda(), want_logits=True).float().cpu()
     print(f'{tag}: worst GPU vs reference {worst[0]:.4f}, vs fp32 math {worst[1]:.4f} (reference noise floor {worst[2]:.4f}); '
           f'argmax differs from the reference token in {flips} of {new.numel()} (row, step) pairs, all inside the band')
+    print(f'{tag}: RMS-relative error vs fp32 math per (row, step): worst GPU over all 32000 logits {rms_worst["gpu_all"]:.5f}, worst real '
+          f'reference bf16 (fixture subsample) {rms_worst["ref_sub"]:.5f}, worst eager bf16 on the card (all logits) {rms_worst["eager_all"]:.5f}; '
+          f'worst per-row ratio GPU / reference: subsample {rms_worst["sub_ratio"]:.3f}, all logits {rms_worst["all_ratio"]:.3f} (printed, not asserted); '
+          f'worst per-step ratio of the row means {rms_worst["mean_ratio"]:.3f}, worst GPU (row, step) / worst reference (row, step) {rms_worst["max_ratio"]:.3f} (bar {RMS_FACTOR} each)')
 
 
 def test_full_width_generate_is_token_identical_on_peaked_weights():
