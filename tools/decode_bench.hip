@@ -667,6 +667,13 @@ int main(int argc, char** argv) {
       CK(launch_gemv_ex(a, EPI_RESIDUAL, 0, s));
     };
     // the same layer with both RMSNorms folded into their projections (5 launches): raw rows in, row scale in the epilogue
+    // OVERLAP_EXP: consecutive launches alternate between TWO streams with no dependency between the streams (launch j and j + 2
+    // stay ordered, j and j + 1 may overlap; the results are garbage, only the timing means something): an upper bound on what
+    // letting launch j + 1 start its weight stream under launch j's tail could buy (it would need a device-side hand-off:
+    // tools/experiments/r3_device_handoff.patch, measured 2.8x SLOWER than one stream).
+    hipStream_t ov[2] = {s, s};
+    int ov_cnt = 0;
+    auto nexts = [&]() -> hipStream_t { return ov[(ov_cnt++) & 1]; };
     auto layer5 = [&](int i) {
       char* base = (char*)pool + ((size_t)(i % 6) * layer_bytes);
       GemvArgs a = {};
@@ -677,22 +684,45 @@ int main(int argc, char** argv) {
       bf16_t* hxf = R + (size_t)8 * ff;   // fragment-ordered hidden rows
       a.X = hxf; a.ldx = d; a.Wp = (const bf16_t*)base; a.C = Y; a.ldc = d; a.N = 3 * d; a.K = d; a.Nvalid = 3 * d; a.R = nullptr;
       a.ssq_in = ssq;
-      CK(launch_gemv_ex(a, EPI_ROPE_KV, 0, s));
+      CK(launch_gemv_ex(a, EPI_ROPE_KV, 0, nexts()));
       DecodeAttnArgs t = {};
       t.o_xf = 1;
       t.Q = Y; t.q_bs = d; t.Kc = a.Kc; t.Vc = a.Vc; t.c_bs = a.c_bs; t.c_hs = a.c_hs; t.O = R; t.o_bs = d;
       t.part = part; t.kbeg = ints + 16; t.cur_len = ints; t.B = M; t.H = H; t.scale = 0.0883883f;
-      CK(launch_decode_attention(t, s));
+      CK(launch_decode_attention(t, nexts()));
       a.X = R; a.Wp = (const bf16_t*)(base + (size_t)3 * d * d * 2); a.C = X; a.R = X; a.ldr = d; a.ldc = d; a.N = d; a.Nvalid = d;
       a.ssq_in = nullptr; a.ssq_out = ssq; a.C_xf = hxf;
-      CK(launch_gemv_ex(a, EPI_RESIDUAL, 0, s));
+      CK(launch_gemv_ex(a, EPI_RESIDUAL, 0, nexts()));
       a.X = hxf; a.Wp = (const bf16_t*)(base + (size_t)4 * d * d * 2); a.C = Y; a.ldc = ff; a.N = 2 * ff; a.Nvalid = ff; a.R = nullptr;
       a.ssq_out = nullptr; a.C_xf = nullptr; a.ssq_in = ssq;
-      CK(launch_gemv_ex(a, EPI_SWIGLU, 0, s));
+      CK(launch_gemv_ex(a, EPI_SWIGLU, 0, nexts()));
       a.X = Y; a.ldx = ff; a.K = ff; a.Wp = (const bf16_t*)(base + ((size_t)4 * d * d + (size_t)2 * d * ff) * 2); a.C = X; a.R = X;
       a.ldr = d; a.ldc = d; a.N = d; a.Nvalid = d; a.ssq_in = nullptr; a.ssq_out = ssq; a.C_xf = hxf;
-      CK(launch_gemv_ex(a, EPI_RESIDUAL, 0, s));
+      CK(launch_gemv_ex(a, EPI_RESIDUAL, 0, nexts()));
     };
+    if (getenv("OVERLAP_EXP")) {
+      CK(hipStreamCreate(&ov[0]));
+      CK(hipStreamCreate(&ov[1]));
+      hipEvent_t j0, j1;
+      CK(hipEventCreate(&j0));
+      CK(hipEventCreate(&j1));
+      for (int rep = 0; rep < 3; ++rep) {
+        for (int i = 0; i < 8; ++i) layer5(i);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0, ov[0]));
+        CK(hipEventRecord(j0, ov[0]));
+        CK(hipStreamWaitEvent(ov[1], j0, 0));
+        for (int i = 0; i < 64; ++i) layer5(i);
+        CK(hipEventRecord(j1, ov[1]));
+        CK(hipStreamWaitEvent(ov[0], j1, 0));
+        CK(hipEventRecord(e1, ov[0]));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("full layer (5 launches) alternating over two unordered streams : %7.2f us per layer\n", ms * 1e3f / 64);
+      }
+      ov[0] = ov[1] = s;
+      CK(hipDeviceSynchronize());
+    }
     float us5 = time_it(layer5);
     float us = time_it(layer);
     us5 = 0.5f * (us5 + time_it(layer5));
