@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, rel_err
+from conftest import GOLDEN, rel_err, rows_ok
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-2
@@ -46,12 +46,14 @@ def test_vision_pool_project_stages(tiny):
     ref_vt = cr.vision_tower(st, TINY, flat)
     vt = eng.vision_encode(flat.cuda())
     assert rel_err(vt, ref_vt) <= TOL
+    rows_ok(vt, ref_vt, 'vision tokens')
     _gold_close(vt, g, 'vt_V3', 37, 41)
     # pooler and projector in isolation (fed with the oracle's inputs)
     emb, mask = cr.pad_embeddings(torch.split(ref_vt, [3, 3]))
     ref_pool = cr.image_pooler(st, TINY, emb, mask)
     pool = eng.pool_views(ref_vt.cuda().contiguous(), [3, 3])
     assert rel_err(pool, ref_pool) <= TOL
+    rows_ok(pool, ref_pool, 'pooled views')
     ref_proj = cr.mm_projector(st, ref_pool)
     assert rel_err(eng.project(ref_pool.cuda().contiguous()), ref_proj) <= TOL
     # chained, against the real reference's output
@@ -79,6 +81,7 @@ def test_view_fusion_variants(tiny):
     gp = model.get_vision_tower().global_forward(synth_images(2, 1, TINY).cuda())
     ref = torch.from_numpy(g['global_pooler_output'])
     assert rel_err(gp, ref) <= TOL
+    rows_ok(gp, ref, 'view reduce / pool')
 
 
 def test_visual_descriptor_embeddings(tiny):
@@ -93,6 +96,7 @@ def test_visual_descriptor_embeddings(tiny):
     ref = cr.mm_projector(st, cr.vision_tower_global(st, TINY, crops))
     assert got.shape == (5, TINY.d_model)
     assert rel_err(got, ref) <= TOL
+    rows_ok(got, ref, 'descriptor embeddings')
 
 
 def test_splice_rows_are_exact_copies(tiny):
@@ -146,6 +150,7 @@ def test_prefill_logits_and_teacher_forced_decode(tiny):
     left_pad = (~mask).sum(-1).tolist()
     logits = eng.prefill(emb.cuda().contiguous(), pos.cuda(), left_pad, want_logits=True)
     assert rel_err(logits, ref_logits) <= TOL
+    rows_ok(logits, ref_logits, 'prefill logits')
     gold = torch.from_numpy(g['rand.logits_sub'])
     assert rel_err(logits[:, ::97], gold) <= TOL
     attn = mask.clone()
@@ -159,6 +164,7 @@ def test_prefill_logits_and_teacher_forced_decode(tiny):
         ref_logits, kv = cr.llama_forward(st, TINY, e, attn, p, kv)
         logits = eng.decode_step(feed.cuda(), want_logits=True)
         assert rel_err(logits, ref_logits) <= TOL, step
+        rows_ok(logits, ref_logits, 'decode logits')
         top2 = torch.topk(ref_logits, 2, dim=-1)
         margin = top2.values[:, 0] - top2.values[:, 1]
         am = logits.argmax(-1).cpu()
