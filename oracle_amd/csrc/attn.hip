@@ -13,6 +13,7 @@
 // second product is simply defined as "the order the first product left the keys in".
 // Rounding points follow the reference's eager path: scores rounded to bf16 after QK^T and again after
 // the scale multiply; probabilities rounded to bf16 before PV (here before the final 1/l).
+#include <stdlib.h>
 #include "common.h"
 #include "kernels.h"
 
@@ -31,13 +32,22 @@ typedef __attribute__((address_space(1))) const void glb_void_t;
 //     wait my DMA of stage s -> barrier -> issue the DMA of tile t+1 -> compute on tile t
 // The XOR swizzles of the K image (ds_read_b128) and of the V image (ds_read_b64_tr_b16) permute 16-B chunks inside a
 // row, so they are applied to the per-lane SOURCE address (LDS-DMA destinations are lane-linear).
-template <int HD>
-__global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a, int order) {
+// QB = 16-row query blocks per wave. QB = 2 (4 waves, 204 VGPRs at head dim 128: 2 waves per SIMD): every K / V fragment read
+// from LDS feeds two MFMAs. QB = 1 (r3: 8 waves of one query block, 124 VGPRs: 4 waves per SIMD): twice the LDS reads per MFMA but
+// twice the waves to hide a wave's serial QK^T -> softmax -> PV chain. Same arithmetic per query row either way (same bits).
+// Measured in the bench (kernel trace): head dim 128 (prefill, pooler) 87.9 -> 82.1 us with QB = 1, head dim 64 (ViT) 94.3 -> 96.4:
+// the default is QB = 1 at 128 and QB = 2 at 64; ORC_ATTN_QB=1 / 2 forces one form for A/B runs. Work-wise the prefill launch is
+// ~14 us of MFMA, ~28 us of softmax VALU and 17.5 (QB = 2) / 35 us (QB = 1) of LDS reads: both forms are bound by the latency of the
+// dependent chain at few waves per SIMD, not by a pipe (the two-tile software pipeline stays undone: DESIGN 9).
+template <int HD, int QB>
+__global__ __launch_bounds__(QB == 2 ? 256 : 512, QB == 2 ? 2 : 4) void attn_kernel(AttnArgs a, int order) {
   constexpr int KB = 64;
+  constexpr int NTHR = QB == 2 ? 256 : 512;
+  constexpr int WROWS = 16 * QB;             // query rows per wave
   constexpr int ROWB = HD * 2;
   constexpr int CH = HD / 8;                 // 16-byte chunks per key row
   constexpr int TILE = KB * ROWB;            // bytes of one K (or V) tile
-  constexpr int RND = KB * CH / 256;         // DMA instructions per wave per operand per tile
+  constexpr int RND = KB * CH / NTHR;        // DMA instructions per wave per operand per tile
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE];   // [stage][K | V]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int g = lane >> 4, r16 = lane & 15;
@@ -65,11 +75,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a, int order) {
   const int kb_ = a.kbeg ? a.kbeg[b] : 0;
   const int ke_ = a.kend ? a.kend[b] : a.Sk;
 
-  bf16x8 qf[2][HD / 32];
-  int qi[2];
+  bf16x8 qf[QB][HD / 32];
+  int qi[QB];
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    const int qrow = qblk + w * 32 + qb * 16 + r16;
+  for (int qb = 0; qb < QB; ++qb) {
+    const int qrow = qblk + w * WROWS + qb * 16 + r16;
     const int qrow_c = qrow < a.Sq ? qrow : a.Sq - 1;
     const bf16_t* qp = a.Q + (size_t)b * a.q_bs + (size_t)h * a.q_hs + (size_t)qrow_c * a.q_ts;
 #pragma unroll
@@ -80,14 +90,16 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a, int order) {
   if (q_hi > a.Sq - 1) q_hi = a.Sq - 1;
   int k_hi = ke_;
   if (a.causal && q_hi + a.q_off + 1 < k_hi) k_hi = q_hi + a.q_off + 1;
-  const int qw_hi = qblk + w * 32 + 31 + a.q_off;            // last key this wave can see under the causal mask
+  const int qw_hi = qblk + w * WROWS + WROWS - 1 + a.q_off;            // last key this wave can see under the causal mask
 
-  f32x4 o[2][HD / 16];
+  f32x4 o[QB][HD / 16];
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb)
+  for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
     for (int i = 0; i < HD / 16; ++i) o[qb][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+  float m[QB], l[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) { m[qb] = -INFINITY; l[qb] = 0.f; }
 
   const int kvb = a.kv_map_on ? a.kv_map.slot[b] : b;        // KV-cache slot of this batch row (prefill into arbitrary slots)
   const bf16_t* kbase = a.K + (size_t)kvb * a.k_bs + (size_t)h * a.k_hs;
@@ -95,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a, int order) {
   // DMA addressing: lane p of round r fills 16-B slot r*256 + p of the image, i.e. key r*(256/CH) + p/CH, chunk p%CH.
   // The per-lane part (key row inside the round, swizzled source chunk) is loop-invariant and the per-round / per-tile
   // part is wave-uniform, so a tile costs no vector address arithmetic; only the tile that crosses Sk clamps per lane.
-  constexpr int KPR = 256 / CH;              // keys per DMA round
+  constexpr int KPR = NTHR / CH;              // keys per DMA round
   const int p_ = w * 64 + lane;
   const int key_p = p_ / CH, cp_ = p_ % CH;
   int ck_r[RND], cv_r[RND];                  // swizzled source chunk (depends on the key, so on r) -- folds to constants
@@ -116,16 +128,16 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a, int order) {
       for (int r = 0; r < RND; ++r) {
         const bf16_t* kr = kbase + (size_t)(k0 + r * KPR) * a.k_ts;       // wave-uniform
         const bf16_t* vr = vbase + (size_t)(k0 + r * KPR) * a.v_ts;
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(kr + koff[r]), (lds_void_t*)(sk + (r * 256 + w * 64) * 16), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(vr + voff[r]), (lds_void_t*)(sv + (r * 256 + w * 64) * 16), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(kr + koff[r]), (lds_void_t*)(sk + (r * NTHR + w * 64) * 16), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(vr + voff[r]), (lds_void_t*)(sv + (r * NTHR + w * 64) * 16), 16, 0, 0);
       }
     } else {
 #pragma unroll
       for (int r = 0; r < RND; ++r) {
         int gk = k0 + r * KPR + key_p;
         gk = gk < a.Sk ? gk : a.Sk - 1;
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(kbase + (size_t)gk * a.k_ts + ck_r[r] * 8), (lds_void_t*)(sk + (r * 256 + w * 64) * 16), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(vbase + (size_t)gk * a.v_ts + cv_r[r] * 8), (lds_void_t*)(sv + (r * 256 + w * 64) * 16), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(kbase + (size_t)gk * a.k_ts + ck_r[r] * 8), (lds_void_t*)(sk + (r * NTHR + w * 64) * 16), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(vbase + (size_t)gk * a.v_ts + cv_r[r] * 8), (lds_void_t*)(sv + (r * NTHR + w * 64) * 16), 16, 0, 0);
       }
     }
   };
@@ -144,21 +156,23 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a, int order) {
     // scores: bf16 rounding after QK^T and again after the scale (the reference's two eager ops). The softmax below is
     // VALU-bound (about 10 vector ops per score against 1/8 of an MFMA), so a tile that no mask touches -- every tile but
     // the padding edge and the causal diagonal -- skips the per-element key tests.
-    const bool need_mask = k0 < kb_ || k0 + KB > ke_ || (a.causal && k0 + KB - 1 > qblk + w * 32 + a.q_off);
-    float s[2][16];
+    const bool need_mask = k0 < kb_ || k0 + KB > ke_ || (a.causal && k0 + KB - 1 > qblk + w * WROWS + a.q_off);
+    float s[QB][16];
 #pragma unroll
     for (int kb4 = 0; kb4 < 4; ++kb4) {
-      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      f32x4 acc[QB];
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) acc[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
       const int key_l = kb4 * 16 + r16;
 #pragma unroll
       for (int kk = 0; kk < HD / 32; ++kk) {
         const int c = kk * 4 + g;
         const bf16x8 kf = *(const bf16x8*)(sK + key_l * ROWB + ((c ^ fK<HD>(key_l)) << 4));
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][kk], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][kk], acc[1], 0, 0, 0);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) acc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qb][kk], acc[qb], 0, 0, 0);
       }
 #pragma unroll
-      for (int qb = 0; qb < 2; ++qb)
+      for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
         for (int r = 0; r < 4; r += 2) {
           float x0, x1;
@@ -170,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a, int order) {
     }
     if (need_mask) {
 #pragma unroll
-      for (int qb = 0; qb < 2; ++qb)
+      for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
           const int key_abs = k0 + (j >> 2) * 16 + 4 * g + (j & 3);
@@ -178,11 +192,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a, int order) {
           s[qb][j] = ok ? s[qb][j] : -INFINITY;
         }
     }
-    bf16x8 pf[2][2];
-    float alpha[2];
+    bf16x8 pf[QB][2];
+    float alpha[QB];
     constexpr float LOG2E = 1.4426950408889634f;
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
+    for (int qb = 0; qb < QB; ++qb) {
       float tm = s[qb][0];
 #pragma unroll
       for (int j = 1; j < 16; ++j) tm = fmaxf(tm, s[qb][j]);
@@ -206,8 +220,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a, int order) {
     }
 #pragma unroll
     for (int dt = 0; dt < HD / 16; ++dt) {
-      o[0][dt] *= alpha[0];
-      o[1][dt] *= alpha[1];
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) o[qb][dt] *= alpha[qb];
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
         const int key_a = hh * 32 + 4 * g + (r16 >> 2);
@@ -217,15 +231,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a, int order) {
         const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p0);
         const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p1);
         const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-        o[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[0][hh], o[0][dt], 0, 0, 0);
-        o[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1][hh], o[1][dt], 0, 0, 0);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) o[qb][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qb][hh], o[qb][dt], 0, 0, 0);
       }
     }
   }
 
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    const int qrow = qblk + w * 32 + qb * 16 + r16;
+  for (int qb = 0; qb < QB; ++qb) {
+    const int qrow = qblk + w * WROWS + qb * 16 + r16;
     if (qrow >= a.Sq) continue;
     const float inv = l[qb] > 0.f ? 1.0f / l[qb] : 0.f;
     bf16_t* op = a.O + (size_t)b * a.o_bs + (size_t)h * a.o_hs + (size_t)qrow * a.o_ts;
@@ -555,10 +569,16 @@ hipError_t launch_attention(const AttnArgs& a, int head_dim, hipStream_t s) {
   // causal: longest query blocks first over the whole grid (measured 111 -> 92 us at 8 x 32 heads x 739 tokens, the
   // tail of late long blocks was 17 % of the kernel); otherwise the query blocks of one (head, row) share an XCD.
   const int order = ((a.H * a.B) & 7) ? 0 : (a.causal ? 2 : 1);
-  if (head_dim == 128)
-    hipLaunchKernelGGL(attn_kernel<128>, grid, dim3(256), 0, s, a, order);
+  static const int qb_env = []() { const char* e = getenv("ORC_ATTN_QB"); return e && (e[0] == '1' || e[0] == '2') ? e[0] - '0' : 0; }();
+  const int qb = qb_env ? qb_env : (head_dim == 128 ? 1 : 2);
+  if (head_dim == 128 && qb == 2)
+    hipLaunchKernelGGL((attn_kernel<128, 2>), grid, dim3(256), 0, s, a, order);
+  else if (head_dim == 128)
+    hipLaunchKernelGGL((attn_kernel<128, 1>), grid, dim3(512), 0, s, a, order);
+  else if (head_dim == 64 && qb == 2)
+    hipLaunchKernelGGL((attn_kernel<64, 2>), grid, dim3(256), 0, s, a, order);
   else if (head_dim == 64)
-    hipLaunchKernelGGL(attn_kernel<64>, grid, dim3(256), 0, s, a, order);
+    hipLaunchKernelGGL((attn_kernel<64, 1>), grid, dim3(512), 0, s, a, order);
   else
     return hipErrorInvalidValue;
   return hipGetLastError();
