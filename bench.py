@@ -204,7 +204,7 @@ def pmc_traffic():
         return None, None
     d = json.load(open(files[-1]))
     for k, v in d['kernels'].items():
-        if 'gemv_pers_kernel<2, 4,' in k or 'gemv_kernel<2, 4,' in k:
+        if 'gemv_pipe_kernel<2, 4,' in k or 'gemv_pers_kernel<2, 4,' in k or 'gemv_kernel<2, 4,' in k:
             return v['hbm_bytes_per_launch'], os.path.relpath(files[-1], ROOT)
     return None, None
 
@@ -596,7 +596,7 @@ def main():
                             'streamed_bytes': dec_phys, 'streamed_GBps': dec_phys / (dec_ms * 1e-3) / 1e9,
                             'streamed_frac_of_hbm_peak': dec_phys / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             'frac_kind': 'frac_of_hbm_peak counts ALGORITHMIC bf16 bytes (effective); streamed_* counts the bytes HBM delivered'},
-            'roofline': {'kernel': ('gemv_pers_kernel<2,SWIGLU,8,2,1,cw> (decode gate/up projection, 22016x4096 bf16 weights streamed as lossless '
+            'roofline': {'kernel': ('gemv_pipe_kernel<2,SWIGLU,8,2,1,cw,2> (decode gate/up projection, 22016x4096 bf16 weights streamed as lossless '
                                     '12-bit blocks)' if gu_phys < prof_bytes else
                                     'gemv_pers_kernel<2,SWIGLU,8,1,1> (decode gate/up projection, 22016x4096 bf16 weights)'), 'bound': 'hbm',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,

@@ -1019,12 +1019,19 @@ hipError_t pick_default(const GemvArgs& a, int ntiles, hipStream_t s) {
     // instead of one 16-wave workgroup: more waves per CU for the decode's vector work, and a flagged block's LDS round trip
     // holds 8 waves at the unit barrier instead of 16 (tools/decode_bench: 22.7 vs 23.6 us; 12 waves on 230 workgroups: 24.8).
     // The bf16 fallback keeps the same K split (so the same bits).
+    // r3: on the compressed stream the pipelined one-unit kernel (688 workgroups of 8 waves, the hardware back-fills) beats the
+    // persistent one on real weights: 21.2 vs 23.6 us on Gaussian weights (tools/decode_bench CW_EXP) -- the persistent loop drains
+    // its queue every iteration and pays 1.6 us for the 4 % of flagged blocks (its side bytes are scalar loads waited for in
+    // place), the pipelined kernel 0.2 us. Same 8-wave K split, so the same bits. The bf16 stream keeps the persistent kernel
+    // (30.6 vs 34.6 us: 1-KiB blocks want fewer, longer streams).
     const int grid2 = units < 480 ? units : 480;
-    if (a.Wc) go_pers<NT, EPI, 8, 2>(a, ntiles, grid2, s);
+    if (a.Wc && pipe_ok<8, 2, 2>(a)) go_pipe<NT, EPI, 8, 2, 2>(a, ntiles, s);
+    else if (a.Wc) go_pers<NT, EPI, 8, 2>(a, ntiles, grid2, s);
     else go_pers<NT, EPI, 8, 1>(a, ntiles, grid2, s);
   } else {
     const int per2 = (units + 511) / 512;
-    go_pers<NT, EPI, 8, 1>(a, ntiles, a.Wc ? (units + per2 - 1) / per2 : grid, s);   // lm_head compressed: grid 500: 32.3 vs 39.4 us
+    if (a.Wc && pipe_ok<8, 2, 2>(a)) go_pipe<NT, EPI, 8, 2, 2>(a, ntiles, s);      // lm_head compressed: 30.3 vs 33.4 us (persistent, grid 500)
+    else go_pers<NT, EPI, 8, 1>(a, ntiles, a.Wc ? (units + per2 - 1) / per2 : grid, s);   // lm_head compressed: grid 500: 32.3 vs 39.4 us
   }
   return hipGetLastError();
 }
@@ -1044,7 +1051,7 @@ hipError_t pick(const GemvArgs& a, int ntiles, int variant, hipStream_t s) {
     case 14: go<NT, EPI, 16, 4, 1>(a, ntiles, s); break;
     case 15: go<NT, EPI, 16, 1, 1>(a, ntiles, s); break;
     // pipelined kernel: 40 + 6 * (W == 16) + 3 * (U - 1) + (NB - 2), W in {8, 16}, U in {1, 2}, NB in {2, 3, 4}
-#define PIPE_CASE(v, W, U_, NB_) case v: if constexpr (EPI == EPI_RESIDUAL || EPI == EPI_ROPE_KV) { if (NT == 2 || !pipe_ok<W, U_, NB_>(a)) return hipErrorInvalidValue; go_pipe<NT, EPI, W, U_, NB_>(a, ntiles, s); break; } else return hipErrorInvalidValue;
+#define PIPE_CASE(v, W, U_, NB_) case v: if constexpr (EPI == EPI_RESIDUAL || EPI == EPI_ROPE_KV || EPI == EPI_SWIGLU || EPI == EPI_F32) { if ((NT == 2 && EPI == EPI_RESIDUAL) || !pipe_ok<W, U_, NB_>(a)) return hipErrorInvalidValue; go_pipe<NT, EPI, W, U_, NB_>(a, ntiles, s); break; } else return hipErrorInvalidValue;
     PIPE_CASE(40, 8, 1, 2) PIPE_CASE(41, 8, 1, 3) PIPE_CASE(42, 8, 1, 4) PIPE_CASE(43, 8, 2, 2) PIPE_CASE(44, 8, 2, 3) PIPE_CASE(45, 8, 2, 4)
     PIPE_CASE(46, 16, 1, 2) PIPE_CASE(47, 16, 1, 3) PIPE_CASE(48, 16, 1, 4) PIPE_CASE(49, 16, 2, 2) PIPE_CASE(50, 16, 2, 3) PIPE_CASE(51, 16, 2, 4)
 #undef PIPE_CASE

@@ -514,6 +514,12 @@ int main(int argc, char** argv) {
         if (sh.epi == EPI_SWIGLU || sh.epi == EPI_F32) {   // persistent configurations on the real data (flags were cleared above: recompress)
           CK(hipMemset(cnt + un, 0, 4));
           CK(launch_compress_weight(gw, sh.N, sh.K, ntu, gc, ge, gp, cnt, cnt + un, 0));
+          for (int variant = 40; variant <= 51; ++variant) {   // one unit per workgroup on the pipelined kernel (W, U, NB)
+            hipError_t e2 = hipSuccess;
+            float t = time_it([&](int i) { hipError_t e = launch_gemv_ex(b, sh.epi, variant, s); if (e != hipSuccess) e2 = e; });
+            if (e2 != hipSuccess) { (void)hipGetLastError(); continue; }
+            printf("%s Gaussian compressed pipe W%-2d U%d NB%d (one unit per workgroup) : %7.2f us\n", sh.name, variant >= 46 ? 16 : 8, ((variant - 40) % 6) / 3 + 1, (variant - 40) % 3 + 2, t);
+          }
           for (int waves : {8, 12, 16})
             for (int u : {1, 2})
               for (int grid : {230, 250, 344, 500}) {
