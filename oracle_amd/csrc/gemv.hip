@@ -1005,10 +1005,9 @@ hipError_t pick_default(const GemvArgs& a, int ntiles, hipStream_t s) {
     if (units <= 256 && EPI == EPI_ROPE_KV && KT >= 16) {
       if (pipe_ok<8, 2, 2>(a)) go_pipe<NT, EPI, 8, 2, 2>(a, ntiles, s);
       else go<NT, EPI, 8, 2, 1>(a, ntiles, s);   // 3-tile units: 18.1 vs 18.4 us
-    } else if (units <= 256 && a.Wc && KT >= 64 && KT <= 128) {
-      if (pipe_ok<16, 2, 2>(a)) go_pipe<NT, EPI, 16, 2, 2>(a, ntiles, s);
-      else go<NT, EPI, 16, 2, 1>(a, ntiles, s);   // o_proj compressed: 7.1 vs 7.4 us
-    } else if (units <= 256) {
+    } else if (units <= 256 && a.Wc && KT >= 64 && KT <= 128 && !pipe_ok<16, 1, 2>(a)) {
+      go<NT, EPI, 16, 2, 1>(a, ntiles, s);   // o_proj compressed on the r2 kernel: 7.1 vs 7.4 us with two k-tiles per buffer
+    } else if (units <= 256) {   // (o_proj compressed, pipelined, on weights that do not fit the Infinity Cache -- REAL_EXP: one k-tile per buffer 7.24 us, two 7.79)
       if (pipe_ok<16, 1, 2>(a)) go_pipe<NT, EPI, 16, 1, 2>(a, ntiles, s);
       else go<NT, EPI, 16, 1, 1>(a, ntiles, s);
     } else go<NT, EPI, 4, 2, 1>(a, ntiles, s);

@@ -552,6 +552,57 @@ int main(int argc, char** argv) {
           }
     }
   }
+  // ---- REAL_EXP: every decode GEMV on REAL compressed Gaussian weights that do not fit the Infinity Cache: R copies of the compressed
+  // matrix (same bytes, different addresses, > 512 MB in all) rotated launch by launch. What the engine sees; use it to tune.
+  if (getenv("REAL_EXP")) {
+    for (const Shape& sh : shapes) {
+      const size_t wbytes = (size_t)sh.N * sh.K * 2;
+      const int ntu = gemv_unit_tiles(sh.epi, sh.N), un = sh.N / 16 / ntu;
+      const size_t nblk = (size_t)sh.N / 16 * sh.K / 32, cbytes = nblk * 768, ebytes = (nblk + 255) & ~(size_t)255;
+      const int NR = (int)(((size_t)600 << 20) / cbytes) + 1;
+      bf16_t* gw;
+      uint8_t *gc, *ge;
+      uint16_t* gp;
+      int* cnt;
+      CK(hipMalloc((void**)&gw, wbytes)); CK(hipMalloc((void**)&gc, cbytes * NR)); CK(hipMalloc((void**)&ge, ebytes * NR));
+      CK(hipMalloc((void**)&gp, (size_t)un * 512)); CK(hipMalloc((void**)&cnt, (size_t)(un + 1) * 4));
+      hipLaunchKernelGGL(gauss_kernel, dim3(4096), dim3(256), 0, 0, gw, wbytes / 2, 99u);
+      CK(hipMemset(cnt + un, 0, 4));
+      CK(launch_compress_weight(gw, sh.N, sh.K, ntu, gc, ge, gp, cnt, cnt + un, 0));
+      CK(hipDeviceSynchronize());
+      for (int r = 1; r < NR; ++r) {
+        CK(hipMemcpy(gc + cbytes * r, gc, cbytes, hipMemcpyDeviceToDevice));
+        CK(hipMemcpy(ge + ebytes * r, ge, nblk, hipMemcpyDeviceToDevice));
+      }
+      GemvArgs a = {};
+      a.X = X; a.ldx = sh.K; a.bias = nullptr; a.R = R; a.ldr = sh.N; a.C = Y;
+      a.ldc = sh.epi == EPI_SWIGLU ? sh.N / 2 : (sh.epi == EPI_ROPE_KV ? d : sh.N);
+      a.M = M; a.N = sh.N; a.K = sh.K; a.Nvalid = sh.epi == EPI_SWIGLU ? sh.N / 2 : sh.N;
+      a.H = H; a.kbeg = ints + 16; a.cur_len = ints; a.cos_tab = cosb; a.sin_tab = sinb;
+      a.maxpos = 4096; a.Kc = Kc; a.Vc = Vc; a.c_bs = (long)H * Tmax * 128; a.c_hs = (long)Tmax * 128;
+      a.ssq_out = ssq; a.x_xf = 1; a.c_xf = 1; a.patch = gp;
+      if (use_meta) { a.row_meta = row_meta; a.row_cos = row_cos; a.row_sin = row_sin; }
+      auto point = [&](int i) { a.Wc = gc + cbytes * (i % NR); a.emin = ge + ebytes * (i % NR); };
+      for (int variant : {0, 40, 41, 43, 44, 46, 47, 49, 50}) {
+        hipError_t err = hipSuccess;
+        float us = time_it([&](int i) { point(i); hipError_t e = launch_gemv_ex(a, sh.epi, variant, s); if (e != hipSuccess) err = e; });
+        if (err != hipSuccess) { (void)hipGetLastError(); continue; }
+        if (variant == 0) printf("%s REAL default          : %7.2f us  (%d copies of %.1f MB)\n", sh.name, us, NR, cbytes * 1e-6);
+        else printf("%s REAL pipe W%-2d U%d NB%d   : %7.2f us\n", sh.name, variant >= 46 ? 16 : 8, ((variant - 40) % 6) / 3 + 1, (variant - 40) % 3 + 2, us);
+      }
+      if (sh.epi == EPI_SWIGLU || sh.epi == EPI_F32)
+        for (int waves : {8, 16})
+          for (int u : {1, 2})
+            for (int grid : {250, 480, 500}) {
+              if (grid > un) continue;
+              hipError_t e2 = hipSuccess;
+              float t = time_it([&](int i) { point(i); hipError_t e = launch_gemv_pers(a, sh.epi, waves, u, grid, s); if (e != hipSuccess) e2 = e; });
+              if (e2 != hipSuccess) { (void)hipGetLastError(); continue; }
+              printf("%s REAL pers W%-2d U%d grid %3d : %7.2f us\n", sh.name, waves, u, grid, t);
+            }
+      CK(hipFree(gw)); CK(hipFree(gc)); CK(hipFree(ge)); CK(hipFree(gp)); CK(hipFree(cnt));
+    }
+  }
   // ---- persistent GEMV: (waves, U, grid) sweep, checked against the default kernel's output
   if (getenv("PERS_EXP")) {
     for (const Shape& sh : shapes) {
