@@ -548,6 +548,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs a) {
 //   * NB register buffers of U k-tiles (template), the patch table is requested FIRST (oldest in the queue).
 // Host side: needs floor((K / 32) / WAVES) >= NB * U (pick_default falls back to gemv_kernel otherwise: tiny models).
 typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+#ifndef PIPE_W_AUX
+#define PIPE_W_AUX 2   // cache policy of the weight stream's buffer loads (gfx950: bit 0 sc0, bit 1 nt, bit 4 sc1): non-temporal. REAL_EXP: without nt
+                       // (0) every launch is 1.3-4 us slower (gate/up 23.7 -> 25.7, lm_head 31.7 -> 35.6); sc0 / sc1 on top of nt change nothing
+#endif
 template <int NT, int EPI, int WAVES, int U, int RH, bool CW, int NB>
 __global__ __launch_bounds__(WAVES * 64) void gemv_pipe_kernel(GemvArgs a) {
   __shared__ __attribute__((aligned(16))) float red[WAVES][NT][RH][64][4];
@@ -642,9 +646,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_pipe_kernel(GemvArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       if constexpr (CW) {
-        wd[nt].r.c = __builtin_bit_cast(u32x3, __builtin_amdgcn_raw_buffer_load_b96(wrs, wlane, (nt * KT + kt) * 768, 2));
+        wd[nt].r.c = __builtin_bit_cast(u32x3, __builtin_amdgcn_raw_buffer_load_b96(wrs, wlane, (nt * KT + kt) * 768, PIPE_W_AUX));
       } else {
-        wd[nt].v = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlane, (nt * KT + kt) * 1024, 2));
+        wd[nt].v = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlane, (nt * KT + kt) * 1024, PIPE_W_AUX));
       }
     }
 #pragma unroll
