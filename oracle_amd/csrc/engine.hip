@@ -835,9 +835,12 @@ static int llama_decode_layers(orc_engine* e, int B, hipStream_t s, bool skip_fi
     a.scale = 0.08838834764831845f;
     HIPCHK(launch_decode_attention(a, s));
     ORCCHK(gemv_ex(e, att, d, L.o, h, h, d, B, EPI_RESIDUAL, s, nullptr, nullptr, e->d_ssq, 1, 0, nullptr, nullptr, nullptr, hxf));
-    const bool sample = e->prof_on && (i % 8 == 0) && e->ev_used < (int)e->ev_a.size();
     // sampled launches carry their own start / stop events (the dispatch's timestamps, not a pair of event commands
-    // around it, which would add the launch boundary)
+    // around it, which would add the launch boundary). An event-carrying launch costs the step ~6 us (measured: 596 samples per
+    // generate() call = 3-4 ms, tools/generate_prof.py), so one launch is sampled every 4th token, at layer 0 / 8 / 16 / 24 in turn
+    // (37 samples per 150-token call).
+    const bool sample = e->prof_on && (e->steps_issued & 3) == 0 && i == ((e->steps_issued >> 2) & 3) * 8 && i < c.n_layers &&
+                        e->ev_used < (int)e->ev_a.size();
     if (!e->fold_norm) HIPCHK(launch_rmsnorm(h, d, L.ln_post, e->d_xn, d, B, d, c.rms_eps, s));
     ORCCHK(gemv_ex(e, e->fold_norm ? hxf : e->d_xn, d, L.gu_dec, nullptr, mlp, c.d_ff, B, EPI_SWIGLU, s, nullptr, nullptr, nullptr, e->fold_norm ? 1 : 0, 1,
                    sample ? e->ev_a[e->ev_used] : nullptr, sample ? e->ev_b[e->ev_used] : nullptr, e->fold_norm ? e->d_ssq : nullptr));
