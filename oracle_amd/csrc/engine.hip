@@ -45,6 +45,7 @@ struct Packed {
   int N = 0, K = 0, Nvalid = 0;   // padded rows / cols, valid rows
   // lossless 12-bit copy for the decode GEMVs (gemv.hip); null = the GEMV streams p
   uint8_t* wc = nullptr; uint8_t* emin = nullptr; uint16_t* patch = nullptr;
+  int wc_group = 0;   // block order inside wc (GemvArgs::wc_group): ORC_DECODE_LAYOUT=rowmajor keeps 0, default kCwGroup
 };
 struct ClipLayer {
   bf16_t *ln1w, *ln1b, *ln2w, *ln2b, *bqkv, *bo, *b1, *b2;
@@ -282,7 +283,9 @@ int compress_for_decode(orc_engine* e, Packed* W, int epi, bool drop_plain, cons
   ORCCHK(e->alloc((void**)&patch, (size_t)units * 256 * 2));
   HIPCHK(hipMalloc((void**)&cnt, (size_t)(units + 1) * 4));
   HIPCHK(hipMemset(cnt + units, 0, 4));
-  HIPCHK(launch_compress_weight(W->p, W->N, W->K, nt_unit, wc, em, patch, cnt, cnt + units, 0));
+  static const int group = []() { const char* l = getenv("ORC_DECODE_LAYOUT"); return l && strcmp(l, "rowmajor") == 0 ? 0 : kCwGroup; }();
+  HIPCHK(launch_compress_weight(W->p, W->N, W->K, nt_unit, wc, em, patch, cnt, cnt + units, 0, group));
+  W->wc_group = group;
   std::vector<int> hc(units + 1);
   HIPCHK(hipMemcpy(hc.data(), cnt, (size_t)(units + 1) * 4, hipMemcpyDeviceToHost));
   HIPCHK(hipFree(cnt));
@@ -744,7 +747,7 @@ static int gemv_ex(orc_engine* e, const bf16_t* X, int ldx, const Packed& W, con
   a.ssq_in = ssq_in; a.n_part = c.d_model / 16; a.norm_d = c.d_model; a.norm_eps = c.rms_eps; a.C_xf = C_xf;
   a.map = e->row_map;
   a.X = X; a.ldx = ldx; a.Wp = W.p; a.bias = nullptr; a.R = R; a.ldr = ldc; a.C = C; a.ldc = ldc;
-  a.Wc = W.wc; a.emin = W.emin; a.patch = W.patch;
+  a.Wc = W.wc; a.emin = W.emin; a.patch = W.patch; a.wc_group = W.wc_group;
   a.M = M; a.N = W.N; a.K = W.K; a.Nvalid = (epi == EPI_SWIGLU) ? W.Nvalid / 2 : W.Nvalid;
   a.H = c.n_heads; a.kbeg = e->d_kbeg; a.cur_len = e->d_curlen; a.cos_tab = e->cos_tab; a.sin_tab = e->sin_tab;
   a.maxpos = e->maxpos; a.Kc = kc; a.Vc = vc; a.c_bs = e->c_bs; a.c_hs = e->c_hs;
@@ -1139,7 +1142,7 @@ extern "C" int orc_test_gemm(const void* x, int M, int K, const void* w, int N, 
   a.ldr = nout; a.C = out; a.ldc = nout; a.M = M; a.N = Np; a.K = Kp; a.Nvalid = nout;
   // use_gemv: 0 = GEMM (automatic kernel choice), 1 = decode GEMV, 2 = 128^2 register-staged GEMM, 3 / 4 = LDS-DMA GEMM with
   // 256-row / 128-row tiles only, 5 = decode GEMV on the lossless 12-bit copy of the weights (must equal 1 bit for bit),
-  // 6 / 7 = 1 / 5 on the r2 kernels (branchy k-loop; must equal the pipelined kernels bit for bit),
+  // 6 / 7 = 1 / 5 on the r2 kernels (branchy k-loop; must equal the pipelined kernels bit for bit), 8 = 5 with row-major compressed blocks,
   // 100 + n = LDS-DMA GEMM with n 256-row m-tiles and 128-row tiles for the remaining rows
   hipError_t err;
   struct LegacyGuard { ~LegacyGuard() { gemv_force_legacy(0); } } legacy_guard;
@@ -1147,6 +1150,8 @@ extern "C" int orc_test_gemm(const void* x, int M, int K, const void* w, int N, 
     gemv_force_legacy(1);
     use_gemv = use_gemv == 6 ? 1 : 5;
   }
+  const int test_group = use_gemv == 8 ? 0 : kCwGroup;   // 8 = 5 with the compressed blocks in row-major order (must equal 5 bit for bit)
+  if (use_gemv == 8) use_gemv = 5;
   if (use_gemv == 5) {
     const int nt_unit = gemv_unit_tiles(epi, Np), units = Np / 16 / nt_unit;
     const size_t nblk = (size_t)(Np / 16) * (Kp / 32);
@@ -1158,7 +1163,7 @@ extern "C" int orc_test_gemm(const void* x, int M, int K, const void* w, int N, 
     HIPCHK(hipMalloc((void**)&patch, (size_t)units * 256 * 2));
     HIPCHK(hipMalloc((void**)&cnt, (size_t)(units + 1) * 4));
     HIPCHK(hipMemsetAsync(cnt + units, 0, 4, s));
-    HIPCHK(launch_compress_weight(wp, Np, Kp, nt_unit, wc, em, patch, cnt, cnt + units, s));
+    HIPCHK(launch_compress_weight(wp, Np, Kp, nt_unit, wc, em, patch, cnt, cnt + units, s, test_group));
     int overflow = 0;
     HIPCHK(hipMemcpyAsync(&overflow, cnt + units, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -1166,7 +1171,7 @@ extern "C" int orc_test_gemm(const void* x, int M, int K, const void* w, int N, 
     if (!overflow) {
       GemvArgs g = {};
       g.map = identity_map();
-      g.X = a.X; g.ldx = a.ldx; g.Wp = nullptr; g.Wc = wc; g.emin = em; g.patch = patch; g.bias = a.bias; g.R = a.R; g.ldr = a.ldr;
+      g.X = a.X; g.ldx = a.ldx; g.Wp = nullptr; g.Wc = wc; g.emin = em; g.patch = patch; g.wc_group = test_group; g.bias = a.bias; g.R = a.R; g.ldr = a.ldr;
       g.C = a.C; g.ldc = a.ldc; g.M = a.M; g.N = a.N; g.K = a.K; g.Nvalid = a.Nvalid;
       err = launch_gemv_ex(g, epi, 0, s);
       HIPCHK(hipStreamSynchronize(s));

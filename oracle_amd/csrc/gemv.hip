@@ -84,12 +84,29 @@ __device__ __forceinline__ bf16x8 cw_decode(const CwReg& r, uint32_t e, const ui
   return __builtin_bit_cast(bf16x8, t);
 }
 
+// Position of block (ntile, kt) inside Wc (GemvArgs::wc_group). Row-major (G = 0) puts the N / 16 workgroups of a launch on regions a
+// fixed stride apart that they walk in step -- which HBM channels are busy at a moment then depends on that stride (K = 11008: the
+// down projection ran 2.2 us above the same bytes read interleaved, tools/decode_bench REAL_EXP). Interleaved: the blocks of k-tiles
+// [g G, (g + 1) G) of ALL n-tiles lie together (the last group may be shorter), n-tile major inside the group, so the launch reads one
+// contiguous window per step whatever N and K are.
+__host__ __device__ __forceinline__ size_t cw_block_index(int G, int ntiles, int KT, int ntile, int kt) {
+  if (G <= 0) return (size_t)ntile * KT + kt;
+  if (G == kCwGroup) {   // the only group size the engine uses: shifts and masks (the kernels' hot loops; wave-uniform scalar work)
+    const int k0 = kt & ~(kCwGroup - 1);
+    const int Gg = KT - k0 < kCwGroup ? KT - k0 : kCwGroup;
+    return (size_t)k0 * ntiles + (size_t)ntile * Gg + (kt - k0);
+  }
+  const int g = kt / G, k0 = g * G;
+  const int Gg = KT - k0 < G ? KT - k0 : G;
+  return (size_t)k0 * ntiles + (size_t)ntile * Gg + (kt - k0);
+}
+
 // Compressor (orc_engine_finalize, once per matrix): one wave per 1-KiB block of the packed bf16 matrix. nt_unit = n-tiles per
 // GEMV unit (the patch table is per unit). cnt[unit] (zeroed by the caller) counts escapes; *overflow is set if a unit
 // has more than 254 non-zero ones (the caller then keeps the matrix uncompressed); escaped zeros share two constant entries.
 __global__ __launch_bounds__(64) void cw_compress_kernel(const bf16_t* __restrict__ Wp, int KT, int nt_unit, uint8_t* __restrict__ Wc,
                                                          uint8_t* __restrict__ emin, uint16_t* __restrict__ patch,
-                                                         int* __restrict__ cnt, int* __restrict__ overflow) {
+                                                         int* __restrict__ cnt, int* __restrict__ overflow, int group, int ntiles) {
   const size_t blk = blockIdx.x;
   const int lane = threadIdx.x;
   const u32x4 v = *(const u32x4*)(Wp + blk * 512 + lane * 8);
@@ -135,7 +152,7 @@ __global__ __launch_bounds__(64) void cw_compress_kernel(const bf16_t* __restric
     lo[j >> 2] |= low << (8 * (j & 3));
     hn |= nib << (j < 4 ? 8 * j : 8 * (j - 4) + 4);
   }
-  uint32_t* dst = (uint32_t*)(Wc + blk * 768 + lane * 12);
+  uint32_t* dst = (uint32_t*)(Wc + cw_block_index(group, ntiles, KT, (int)(blk / KT), (int)(blk % KT)) * 768 + lane * 12);
   dst[0] = lo[0]; dst[1] = lo[1]; dst[2] = hn;
   if (lane == 0) {
     emin[blk] = (uint8_t)(eh | (flagged ? 0x80 : 0));
@@ -463,7 +480,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_kernel(GemvArgs a) {
         for (int nt = 0; nt < NT; ++nt) {
           if constexpr (CW) {
             const size_t blk = blk0 + (size_t)nt * KT + kt;
-            dst[u][nt].r.c = __builtin_nontemporal_load((const u32x3*)(a.Wc + blk * 768 + lane * 12));
+            dst[u][nt].r.c = __builtin_nontemporal_load((const u32x3*)(a.Wc + cw_block_index(a.wc_group, a.N >> 4, KT, ntile0 + nt, kt) * 768 + lane * 12));
             ed[u][nt] = cw_base_byte(cw_base_word(a.emin, blk), blk);
           } else {
             dst[u][nt].v = __builtin_nontemporal_load((const bf16x8*)(wp[nt] + (size_t)kt * 512));
@@ -612,8 +629,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_pipe_kernel(GemvArgs a) {
   const size_t blk0 = (size_t)ntile0 * KT;
   // weights through a descriptor over this unit's blocks (offsets stay inside the unit: 32 bits are plenty)
   const uint32_t w_bytes = (uint32_t)NT * (uint32_t)KT * (CW ? 768u : 1024u);
+  // CW with interleaved blocks (wc_group > 0): the descriptor spans the whole matrix (host: < 2 GiB), offsets from cw_block_index
+  const bool ilv = CW && a.wc_group > 0;
+  const int ntiles_all = a.N >> 4;
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-      CW ? (void*)(a.Wc + blk0 * 768) : (void*)(a.Wp + blk0 * 512), 0, (a.dbg & 2) ? 0 : (int)w_bytes, 0x00020000);
+      CW ? (void*)(ilv ? a.Wc : a.Wc + blk0 * 768) : (void*)(a.Wp + blk0 * 512), 0,
+      (a.dbg & 2) ? 0 : (int)(ilv ? (uint32_t)ntiles_all * (uint32_t)KT * 768u : w_bytes), 0x00020000);
   const int wlane = lane * (CW ? 12 : 16);
   // CW: the side bytes of ALL this wave's blocks, one byte load per n-tile (lane i <- k-tile index i; host: nk <= 64), read
   // back with v_readlane at decode time. (r2 fetched each block's byte by s_load next to its weight load: scalar loads
@@ -646,7 +667,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_pipe_kernel(GemvArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       if constexpr (CW) {
-        wd[nt].r.c = __builtin_bit_cast(u32x3, __builtin_amdgcn_raw_buffer_load_b96(wrs, wlane, (nt * KT + kt) * 768, PIPE_W_AUX));
+        const int boff = ilv ? (int)cw_block_index(kCwGroup, ntiles_all, KT, ntile0 + nt, kt) : nt * KT + kt;   // host: wc_group is 0 or kCwGroup
+        wd[nt].r.c = __builtin_bit_cast(u32x3, __builtin_amdgcn_raw_buffer_load_b96(wrs, wlane, boff * 768, PIPE_W_AUX));
       } else {
         wd[nt].v = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlane, (nt * KT + kt) * 1024, PIPE_W_AUX));
       }
@@ -825,7 +847,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemv_pers_kernel(GemvArgs a, int u
         for (int nt = 0; nt < NT; ++nt) {
           if constexpr (CW) {
             const size_t blk = lblk + (size_t)nt * KT + kt;
-            dst[u][nt].r.c = __builtin_nontemporal_load((const u32x3*)(a.Wc + blk * 768 + lane * 12));
+            dst[u][nt].r.c = __builtin_nontemporal_load((const u32x3*)(a.Wc + cw_block_index(a.wc_group, a.N >> 4, KT, (int)(lblk / KT) + nt, kt) * 768 + lane * 12));
             ed[u][nt] = cw_base_byte(cw_base_word(a.emin, blk), blk);
           } else {
             dst[u][nt].v = __builtin_nontemporal_load((const bf16x8*)(lw + ((size_t)nt * KT + kt) * 512));
@@ -961,7 +983,7 @@ template <int WAVES, int U, int NB>
 bool pipe_ok(const GemvArgs& a) {
   const int KT = a.K >> 5;
   return !g_gemv_legacy && KT / WAVES >= NB * U && (KT + WAVES - 1) / WAVES <= 64 && (long)a.M * a.ldx * 2 < (1l << 31) &&
-         (long)((a.M + 15) / 16) * 16 * a.K * 2 < (1l << 31);
+         (long)((a.M + 15) / 16) * 16 * a.K * 2 < (1l << 31) && (a.wc_group <= 0 || !a.Wc || (long)(a.N / 16) * KT * 768 < (1l << 31));
 }
 template <int NT, int EPI, int WAVES, int U, int RH, bool CW, int NB>
 void go_pipe_cw(const GemvArgs& a, int ntiles, hipStream_t s) {
@@ -1072,6 +1094,7 @@ hipError_t launch_gemv_ex(const GemvArgs& a, int epi, int variant, hipStream_t s
   if (a.M <= 0) return hipSuccess;
   if (a.M > 32 || (a.K & 31) || (a.N & 15) || (!a.Wp && !a.Wc)) return hipErrorInvalidValue;
   if (a.Wc && (!a.emin || !a.patch)) return hipErrorInvalidValue;
+  if (a.Wc && a.wc_group != 0 && a.wc_group != kCwGroup) return hipErrorInvalidValue;
   const int ntiles = a.N / 16;
   switch (epi) {
     case EPI_NONE: return pick<1, EPI_NONE>(a, ntiles, variant, s);
@@ -1140,13 +1163,13 @@ int gemv_unit_tiles(int epi, int N) {
   return 1;
 }
 hipError_t launch_compress_weight(const bf16_t* Wp, int N, int K, int nt_unit, uint8_t* Wc, uint8_t* emin, uint16_t* patch, int* cnt,
-                                  int* overflow_dev, hipStream_t s) {
-  if ((N & 15) || (K & 31) || nt_unit < 1 || (N / 16) % nt_unit) return hipErrorInvalidValue;
+                                  int* overflow_dev, hipStream_t s, int group) {
+  if ((N & 15) || (K & 31) || nt_unit < 1 || (N / 16) % nt_unit || group < 0) return hipErrorInvalidValue;
   const int ntiles = N / 16, KT = K / 32, units = ntiles / nt_unit;
   hipError_t err = hipMemsetAsync(cnt, 0, (size_t)units * 4, s);
   if (err != hipSuccess) return err;
   err = hipMemsetAsync(patch, 0, (size_t)units * 256 * 2, s);
   if (err != hipSuccess) return err;
-  hipLaunchKernelGGL(cw_compress_kernel, dim3((unsigned)((size_t)ntiles * KT)), dim3(64), 0, s, Wp, KT, nt_unit, Wc, emin, patch, cnt, overflow_dev);
+  hipLaunchKernelGGL(cw_compress_kernel, dim3((unsigned)((size_t)ntiles * KT)), dim3(64), 0, s, Wp, KT, nt_unit, Wc, emin, patch, cnt, overflow_dev, group, ntiles);
   return hipGetLastError();
 }

@@ -67,6 +67,11 @@ struct GemvArgs {
   // emin[block]: bits 0-6 = (smallest coded exponent field) / 2, bit 7 = the block has escaped elements;
   // patch: true bf16 bits of the escaped elements, 256 entries per GEMV unit
   const uint8_t* Wc = nullptr; const uint8_t* emin = nullptr; const uint16_t* patch = nullptr;
+  // order of the 768-B blocks inside Wc (cw_block_index, gemv.hip): 0 = row-major, block (ntile, kt) at ntile * KT + kt; G > 0 = interleaved in
+  // groups of G k-tiles -- all n-tiles' blocks of k-tiles [g G, (g + 1) G) lie together -- so that the workgroups of a launch, which walk
+  // K in step, read ONE contiguous window of the matrix at a time instead of N / 16 regions a fixed stride apart. emin / patch keep the
+  // row-major block numbering.
+  int wc_group = 0;
   // optional (host side only): HIP events that bracket exactly this kernel's execution (hipExtLaunchKernelGGL start /
   // stop events = the dispatch's own timestamps, what rocprofv3's kernel trace reports), for orc_profile_read
   void* ev_start; void* ev_stop;
@@ -82,8 +87,9 @@ void gemv_force_legacy(int on);   // tests / tools: 1 = run the r2 kernels (bran
 // lossless 12-bit compression of a packed matrix for the decode GEMVs (gemv.hip): Wc N*K*3/2 bytes, emin N/16*K/32 bytes (+3 pad),
 // patch (N/16/nt_unit)*256 uint16, cnt N/16/nt_unit ints; *overflow_dev is set when a unit has more than 254 non-zero escapes (escaped zeros share two constant entries)
 int gemv_unit_tiles(int epi, int N);
+constexpr int kCwGroup = 16;   // the decode GEMVs' window: 8 waves x 2 k-tiles or 16 waves x 1 per workgroup step
 hipError_t launch_compress_weight(const bf16_t* Wp, int N, int K, int nt_unit, uint8_t* Wc, uint8_t* emin, uint16_t* patch, int* cnt,
-                                  int* overflow_dev, hipStream_t s);
+                                  int* overflow_dev, hipStream_t s, int group = kCwGroup);
 // colscale (bf16 [K], may be null): Wp holds bf16(W[n][k] * colscale[k])
 hipError_t launch_pack_weight(const bf16_t* W, int Nsrc, int K, const int* rowmap, bf16_t* Wp, int Np, int Kp,
                               hipStream_t s, const bf16_t* colscale = nullptr);

@@ -246,7 +246,7 @@ def test_gemm(x, w, bias=None, residual=None, epilogue='none', use_gemv=False, k
     nout = n // 2 if epilogue == 'swiglu' else n
     out = torch.empty(m, nout, dtype=torch.float32 if epilogue == 'f32' else torch.bfloat16, device=x.device)
     _lib.check(l.orc_test_gemm(_ptr(x), m, k, _ptr(w), n, _ptr(bias), _ptr(residual), EPI[epilogue],
-                               {'cw': 5, 'legacy': 6, 'legacy_cw': 7}[use_gemv] if isinstance(use_gemv, str) else 1 if use_gemv else (100 + int(kernel[3:]) if isinstance(kernel, str) and kernel.startswith('mix') else {None: 0, 'tile128': 2, 'dma256': 3, 'dma128': 4}[kernel]),
+                               {'cw': 5, 'legacy': 6, 'legacy_cw': 7, 'cw_rowmajor': 8}[use_gemv] if isinstance(use_gemv, str) else 1 if use_gemv else (100 + int(kernel[3:]) if isinstance(kernel, str) and kernel.startswith('mix') else {None: 0, 'tile128': 2, 'dma256': 3, 'dma128': 4}[kernel]),
                                _ptr(out), _stream()), 'orc_test_gemm')
     return out
 

@@ -324,6 +324,27 @@ def test_compressed_weight_stream_on_non_gaussian_weights(kind, epi, N, K):
     assert torch.equal(plain.view(v), packed.view(v))
 
 
+@pytest.mark.parametrize('M', [1, 8, 17])
+@pytest.mark.parametrize('epi,N,K', [('residual', 4096, 11008), ('residual', 4096, 4096), ('swiglu', 22016, 4096), ('f32', 32000, 4096),
+                                     ('residual', 512, 1408), ('none', 1024, 3072), ('none', 768, 832)])
+def test_interleaved_compressed_blocks_equal_row_major(epi, N, K, M):
+    """r3: the 768-B blocks of a compressed decode matrix are stored interleaved in groups of 16 k-tiles (all n-tiles' blocks of a group
+    together, the last group shorter when K / 32 is not a multiple of 16: K = 11008 -> 344 = 21 x 16 + 8, K = 1408 -> 44, K = 832 -> 26),
+    so that a launch reads one contiguous window per step (gemv.hip cw_block_index). Same data, different placement: every output bit
+    equals the row-major order's, on the pipelined kernels, the persistent / r2 fallbacks (short K) and the r2 kernels forced."""
+    from oracle_amd import engine as E
+    d = _dev()
+    x = _rand((M, K), 81).to(d)
+    res = _rand((M, N), 83).to(d) if epi == 'residual' else None
+    w = _nasty_weights(N, K, 84).to(d) if N * K < 5e7 else _rand((N, K), 82, 0.02).to(d)
+    v = torch.int32 if epi == 'f32' else torch.int16
+    a = E.test_gemm(x, w, None, res, epi, use_gemv='cw')
+    b = E.test_gemm(x, w, None, res, epi, use_gemv='cw_rowmajor')
+    c = E.test_gemm(x, w, None, res, epi, use_gemv='legacy_cw')
+    assert torch.equal(a.view(v), b.view(v))
+    assert torch.equal(a.view(v), c.view(v))
+
+
 @pytest.mark.parametrize('M', [1, 8, 16, 17, 32])
 @pytest.mark.parametrize('epi,N,K', [('residual', 4096, 11008), ('residual', 4096, 4096), ('none', 12288, 4096), ('residual', 512, 1408),
                                      ('none', 4096, 2048), ('residual', 1024, 768 * 4)])

@@ -93,8 +93,7 @@ __global__ void dist_kernel(uint16_t* p, int N, int K, int kind, uint32_t seed) 
 }
 struct Shape { const char* name; int N, K, epi; };
 int gemv_unit_tiles(int epi, int N);
-hipError_t launch_compress_weight(const bf16_t* Wp, int N, int K, int nt_unit, uint8_t* Wc, uint8_t* emin, uint16_t* patch, int* cnt,
-                                  int* overflow_dev, hipStream_t s);
+
 hipError_t launch_gemv_pers(const GemvArgs& a, int epi, int waves, int u, int grid, hipStream_t s);
 
 int main(int argc, char** argv) {
@@ -568,7 +567,8 @@ int main(int argc, char** argv) {
       CK(hipMalloc((void**)&gp, (size_t)un * 512)); CK(hipMalloc((void**)&cnt, (size_t)(un + 1) * 4));
       hipLaunchKernelGGL(gauss_kernel, dim3(4096), dim3(256), 0, 0, gw, wbytes / 2, 99u);
       CK(hipMemset(cnt + un, 0, 4));
-      CK(launch_compress_weight(gw, sh.N, sh.K, ntu, gc, ge, gp, cnt, cnt + un, 0));
+      const int grp = getenv("ROWMAJOR") ? 0 : kCwGroup;   // ROWMAJOR=1: the r2 block order
+      CK(launch_compress_weight(gw, sh.N, sh.K, ntu, gc, ge, gp, cnt, cnt + un, 0, grp));
       CK(hipDeviceSynchronize());
       for (int r = 1; r < NR; ++r) {
         CK(hipMemcpy(gc + cbytes * r, gc, cbytes, hipMemcpyDeviceToDevice));
@@ -580,7 +580,7 @@ int main(int argc, char** argv) {
       a.M = M; a.N = sh.N; a.K = sh.K; a.Nvalid = sh.epi == EPI_SWIGLU ? sh.N / 2 : sh.N;
       a.H = H; a.kbeg = ints + 16; a.cur_len = ints; a.cos_tab = cosb; a.sin_tab = sinb;
       a.maxpos = 4096; a.Kc = Kc; a.Vc = Vc; a.c_bs = (long)H * Tmax * 128; a.c_hs = (long)Tmax * 128;
-      a.ssq_out = ssq; a.x_xf = 1; a.c_xf = 1; a.patch = gp;
+      a.ssq_out = ssq; a.x_xf = 1; a.c_xf = 1; a.patch = gp; a.wc_group = grp;
       if (use_meta) { a.row_meta = row_meta; a.row_cos = row_cos; a.row_sin = row_sin; }
       auto point = [&](int i) { a.Wc = gc + cbytes * (i % NR); a.emin = ge + ebytes * (i % NR); };
       for (int variant : {0, 40, 41, 43, 44, 46, 47, 49, 50}) {
