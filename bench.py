@@ -485,7 +485,7 @@ def main():
     cap_new = max(a.new_tokens, 300 if a.lengths == 'both' else 16)   # the ragged leg decodes up to the reference's 300
     # KV-cache slots: the ragged leg decodes a.batch rows and prefills the next batch ahead into as many spare slots
     n_slots = 64 if a.lengths == 'both' else a.batch
-    eng = Engine(dims, max_batch=n_slots, max_seq=T + cap_new + 8, max_images=a.batch * a.views,
+    eng = Engine(dims, max_batch=n_slots, max_seq=int(os.environ.get('ORC_BENCH_MAX_SEQ', T + cap_new + 8)), max_images=a.batch * a.views,
                  max_new_tokens=cap_new, pad_token_id=0, eos_token_id=-1, device=dev)
     eng.load_state(state)
     del state
