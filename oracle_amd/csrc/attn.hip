@@ -38,7 +38,10 @@ typedef __attribute__((address_space(1))) const void glb_void_t;
 // Measured in the bench (kernel trace): head dim 128 (prefill, pooler) 87.9 -> 82.1 us with QB = 1, head dim 64 (ViT) 94.3 -> 96.4:
 // the default is QB = 1 at 128 and QB = 2 at 64; ORC_ATTN_QB=1 / 2 forces one form for A/B runs. Work-wise the prefill launch is
 // ~14 us of MFMA, ~28 us of softmax VALU and 17.5 (QB = 2) / 35 us (QB = 1) of LDS reads: both forms are bound by the latency of the
-// dependent chain at few waves per SIMD, not by a pipe (the two-tile software pipeline stays undone: DESIGN 9).
+// dependent chain at few waves per SIMD, not by a pipe (the two-tile software pipeline stays undone: DESIGN 9). Neither more
+// independent workgroups per CU (64-row workgroups of 4 waves on 32-key tiles, four per CU: 88 -> 101 us; ViT five per CU: 96 -> 99),
+// nor 32-key tiles at 8 waves (96 us), nor the ring stage as a compile-time constant (~25 fewer VALU per tile: 89.3 -> 89.3 us) moved
+// it: profiles/r3/attn_bench_variants.log, tools/experiments/r3_attn_variants.patch.
 template <int HD, int QB>
 __global__ __launch_bounds__(QB == 2 ? 256 : 512, QB == 2 ? 2 : 4) void attn_kernel(AttnArgs a, int order) {
   constexpr int KB = 64;
