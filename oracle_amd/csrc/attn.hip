@@ -41,7 +41,10 @@ typedef __attribute__((address_space(1))) const void glb_void_t;
 // dependent chain at few waves per SIMD, not by a pipe (the two-tile software pipeline stays undone: DESIGN 9). Neither more
 // independent workgroups per CU (64-row workgroups of 4 waves on 32-key tiles, four per CU: 88 -> 101 us; ViT five per CU: 96 -> 99),
 // nor 32-key tiles at 8 waves (96 us), nor the ring stage as a compile-time constant (~25 fewer VALU per tile: 89.3 -> 89.3 us) moved
-// it: profiles/r3/attn_bench_variants.log, tools/experiments/r3_attn_variants.patch.
+// it, nor did v_permlane16/32_swap in place of the four ds_bpermute of the softmax reductions (bit-equal, 90.6 -> 90.4 us):
+// profiles/r3/attn_bench_variants.log, tools/experiments/r3_attn_*.patch. The counters there say why: VALU issue is 62 % of the launch
+// and MFMA 26 %, almost serially -- the ~1100 VALU cycles of softmax per wave and tile (two bf16 roundings per score as the
+// reference makes them, 17 v_exp) are the floor of this formulation, LDS conflicts are zero.
 template <int HD, int QB>
 __global__ __launch_bounds__(QB == 2 ? 256 : 512, QB == 2 ? 2 : 4) void attn_kernel(AttnArgs a, int order) {
   constexpr int KB = 64;
