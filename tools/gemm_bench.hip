@@ -23,10 +23,11 @@ int main(int argc, char** argv) {
       {"square 4096      ", 4096, 4096, 4096, EPI_NONE}, {"square 8192      ", 8192, 8192, 8192, EPI_NONE},   // the guide's template shapes
   };
   bf16_t *X, *W, *R, *C, *bias;
-  CK(hipMalloc((void**)&X, (size_t)Mv * 11008 * 2)); CK(hipMalloc((void**)&W, (size_t)22016 * 4096 * 2 * 2));   // X >= 8192 x 8192, W >= 2 x 8192 x 8192
+  const size_t w_elems = getenv("BIGK") ? (size_t)22016 * (16384 + 4096) : (size_t)22016 * 4096 * 2;
+  CK(hipMalloc((void**)&X, (size_t)Mv * 11008 * 2)); CK(hipMalloc((void**)&W, w_elems * 2));   // X >= 8192 x 8192, W >= 2 x 8192 x 8192
   CK(hipMalloc((void**)&R, (size_t)Mv * 4096 * 2)); CK(hipMalloc((void**)&C, (size_t)Mv * 12288 * 2)); CK(hipMalloc((void**)&bias, 65536));
   hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, X, (size_t)Mv * 11008, 1u);
-  hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, W, (size_t)22016 * 4096 * 2, 2u);
+  hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, W, w_elems, 2u);
   hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, R, (size_t)Mv * 4096, 3u);
   hipLaunchKernelGGL(fill_kernel, dim3(64), dim3(256), 0, 0, bias, 32768, 4u);
   CK(hipDeviceSynchronize());
@@ -35,6 +36,27 @@ int main(int argc, char** argv) {
     GemmArgs a; a.X = X; a.ldx = 4096; a.Wp = W; a.bias = bias; a.R = R; a.ldr = 4096; a.C = C; a.ldc = 4096; a.M = Mp; a.N = 4096; a.K = 4096; a.Nvalid = 4096;
     for (int i = 0; i < 1500; ++i) CK(launch_gemm(a, EPI_NONE, 0));
     CK(hipDeviceSynchronize());
+  }
+  if (getenv("BIGK")) {
+    // Is the prefill gate/up launch's fabric traffic (PMC FETCH_SIZE 2.04 GB against 0.36 GB of algorithmic bytes: every tile re-reads
+    // its operand panels past the 4-MiB L2) a cost? Its operands (228 MB) fit the 256-MiB Infinity Cache; the same launch with K x 4
+    // (915 MB of operands, 3.6 x the cache) cannot be served from it. Equal TFLOP/s = the re-reads are not what bounds the kernel.
+    const Shape big[] = {{"prefill gu swiglu      ", Mp, 22016, 4096, EPI_SWIGLU}, {"prefill gu swiglu K x 4", Mp, 22016, 16384, EPI_SWIGLU}};
+    for (const Shape& sh : big) {
+      GemmArgs a; a.X = X; a.ldx = sh.K; a.Wp = W; a.bias = bias; a.R = R; a.ldr = sh.N; a.C = C;
+      a.ldc = sh.N / 2; a.M = sh.M; a.N = sh.N; a.K = sh.K; a.Nvalid = a.ldc;
+      gemm_force_kernel(0);
+      for (int i = 0; i < 4; ++i) CK(launch_gemm(a, sh.epi, 0));
+      CK(hipEventRecord(e0, 0));
+      const int iters = 10;
+      for (int i = 0; i < iters; ++i) { a.Wp = W + (size_t)(i & 1) * 22016 * 4096; CK(launch_gemm(a, sh.epi, 0)); }
+      CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      const double us = ms * 1e3 / iters;
+      printf("%s M=%5d N=%5d K=%5d operands %4.0f MB : %8.1f us  %7.1f TFLOP/s\n", sh.name, sh.M, sh.N, sh.K,
+             ((double)sh.M * sh.K + (double)sh.N * sh.K) * 2e-6, us, 2.0 * sh.M * sh.N * sh.K / us * 1e-6);
+    }
+    return 0;
   }
   for (const Shape& sh : shapes)
     for (int force = 0; force <= 3; ++force) {
